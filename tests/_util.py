@@ -1,0 +1,100 @@
+"""Shared helpers for the parity tests (oracle side).  The oracle is the CHECKER, never the product."""
+import os
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from detfill import det_fill_module, det_uniform
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+TINY = dict(embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], ape=True, drop_path_rate=0.0)
+TINY_PITCH = dict(embed_dim=32, depths=[3, 2, 1, 2], num_heads=[1, 2, 4, 8], ape=True, drop_path_rate=0.0)
+TCFG = dict(embed_dim=96, depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24], ape=True, drop_path_rate=0.0)
+
+# parameters whose true gradient is identically zero (a bias in front of BatchNorm; the key bias, to
+# which softmax is invariant): their computed gradients are rounding noise, compared with atol only.
+ZERO_GRAD_KEYS = ("patch_embed.proj.0.bias", "patch_embed.proj.3.bias", "k_linear.bias")
+
+
+def golden(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def sub(t, n=2048):
+    f = t.detach().reshape(-1)
+    step = max(1, f.numel() // n)
+    return f[::step][:n].clone(), step
+
+
+def model_inputs(shape, tag):
+    return det_uniform(shape, tag + ":input", 1.0)
+
+
+def loss_weights(outs, tag):
+    return [det_uniform(tuple(o.shape), f"{tag}:lossw{i}", 1.0) for i, o in enumerate(outs)]
+
+
+def build_filled(cls, cfg, pano, tag, train=True):
+    m = cls(**cfg, pano_mode=pano)
+    det_fill_module(m, tag)
+    nn.Module.train(m, train)
+    return m
+
+
+def run_and_collect(m, shape, tag, device="cpu", subsample_out=None):
+    """Mirror of oracle/gen_golden.py::run_model for any implementation of the backbone."""
+    x = model_inputs(shape, tag).to(device).requires_grad_(True)
+    outs = m(x)
+    ws = loss_weights(outs, tag)
+    loss = sum((o * w.to(device)).sum() for o, w in zip(outs, ws))
+    loss.backward()
+    res = {}
+    for i, o in enumerate(outs):
+        if subsample_out:
+            res[f"out{i}_sub"] = sub(o, subsample_out)[0].cpu()
+            res[f"out{i}_stats"] = torch.stack([o.mean(), o.abs().mean(), o.std()]).detach().cpu()
+        else:
+            res[f"out{i}"] = o.detach().cpu()
+    res["dx_sub"] = sub(x.grad, 8192)[0].cpu()
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            res[f"grad:{k}"] = sub(p.grad, 1024)[0].cpu()
+            res[f"gnorm:{k}"] = p.grad.double().norm().float().cpu()
+    for k, b in m.named_buffers():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            res[f"buf:{k}"] = b.detach().cpu().clone()
+    return res
+
+
+def compare_to_golden(res, gold, rtol, atol, grad_rtol=None, grad_atol_frac=None, skip_noise=True):
+    """Outputs/dx: allclose(rtol, atol).  Param grads: |diff| <= grad_rtol*|ref| + grad_atol_frac*max|ref|."""
+    grad_rtol = rtol if grad_rtol is None else grad_rtol
+    grad_atol_frac = 1e-5 if grad_atol_frac is None else grad_atol_frac
+    bad = []
+    for k in gold.files:
+        if k.startswith(("gstep:", "out")) and k.endswith("_step") or k in ("dx_step", "dx_stats", "as_shimmed"):
+            continue
+        if k.startswith("gstep:"):
+            continue
+        if k not in res:
+            bad.append(f"missing {k}")
+            continue
+        ref = torch.from_numpy(np.asarray(gold[k])).float()
+        got = res[k].float()
+        if got.shape != ref.shape:
+            bad.append(f"shape {k}: {tuple(got.shape)} vs {tuple(ref.shape)}")
+            continue
+        if k.startswith(("grad:", "gnorm:", "dx_sub")):
+            if skip_noise and any(z in k for z in ZERO_GRAD_KEYS):
+                continue
+            scale = ref.abs().max().item()
+            tol = grad_rtol * ref.abs() + grad_atol_frac * max(scale, 1e-6)
+        else:
+            tol = rtol * ref.abs() + atol
+        err = (got - ref).abs()
+        if not bool((err <= tol).all()):
+            i = int((err - tol).argmax())
+            bad.append(f"{k}: max excess at {i}: got {got.reshape(-1)[i].item():.6g} ref {ref.reshape(-1)[i].item():.6g}")
+    assert not bad, "\n".join(bad[:20])
