@@ -1,0 +1,194 @@
+/*
+ * pswin.h -- C ABI of libpswin_hip.so: the MI355X (gfx950) kernels behind the PanoSwin windowed-attention
+ * hot path.
+ *
+ * The reference (1069066484/PanoSwinTransformerObjectDetection) has no native code and no FFI: every
+ * step of the path is eager PyTorch inside mmdet/models/backbones/simple_panoswin_transformer.py ("HOT").
+ * Each entry point below therefore names the reference *Python* function(s) it replaces (file:line
+ * relative to the reference root); INTEGRATION.md shows the ctypes binding a reference maintainer adds.
+ *
+ * Conventions
+ *   - plain C: raw device pointers, explicit sizes, no torch types.  `stream` is a hipStream_t passed as
+ *     void* (NULL = the default stream).  The caller owns every buffer including workspaces; the library
+ *     allocates nothing, keeps no global state and is thread-safe (the caller sets the device).
+ *   - every function returns 0 on success, a negative PSWIN_ERR_* for a rejected argument, or a positive
+ *     hipError_t from the launch.  Nothing aborts or throws.
+ *   - launches are asynchronous on `stream`; no function synchronises.
+ *   - "rows" are feature vectors of C contiguous elements; tensors are dense row-major.
+ *   - dtype codes: PSWIN_F32 = 0, PSWIN_BF16 = 1 (bf16 = upper 16 bits of an IEEE f32, RNE conversion).
+ *   - window size is 7 (49 tokens) and head_dim is 32 in every attention entry point, as in every
+ *     configuration the reference ships (the swin model configs under configs/_base_/models: window_size=7, C/heads=32).
+ */
+#ifndef PSWIN_H_
+#define PSWIN_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSWIN_ABI_VERSION 1
+
+#define PSWIN_F32 0
+#define PSWIN_BF16 1
+
+#define PSWIN_MODE_PLANAR 0
+#define PSWIN_MODE_PANO 1
+
+#define PSWIN_OK 0
+#define PSWIN_ERR_ARG (-1)         /* null pointer, non-positive size, misaligned or inconsistent sizes */
+#define PSWIN_ERR_UNSUPPORTED (-2) /* valid request outside what the kernels are specialised for */
+
+#define PSWIN_WS 7        /* window size */
+#define PSWIN_WTOK 49     /* tokens per window */
+#define PSWIN_WPAD 64     /* tokens per window padded to the MFMA tile */
+#define PSWIN_HEAD_DIM 32
+
+int pswin_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Index maps (bit-exact integer work)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Host helper: padded grid of the window layout.
+ * pano  : the north-south layout [2H, ceil(W/2)] padded to multiples of 7 (HOT:337-353, 486-491)
+ * planar: [H, W] padded to multiples of 7 (HOT:486-491).
+ * Writes Hp, Wp and the number of windows per image.  Pure host arithmetic, no launch. */
+int pswin_window_grid(int mode, int H, int W, int* Hp, int* Wp, int* n_windows);
+
+/* Window map and its inverse, on the device.
+ * Replaces the chain WindowTransition.forward -> pad_x -> window_partition (HOT:376-409, 486-491, 64-75)
+ * and, for `inv`, crop -> WindowTransition.forward(reverse=True) after window_reverse (HOT:78-92, 516-528).
+ *   map[slot] , slot = window*49 + token : flat source token h*W+w, or -1 for a zero (padding) slot
+ *   inv[h*W+w]                            : the slot that holds this token (every token has exactly one)
+ * pano  : roll W by +shift, east-west -> north-south fold, roll H by +shift   (closed form)
+ * planar: pad, then roll by (-shift, -shift)                                  (closed form)
+ * map: int32 [n_windows*49]; inv: int32 [H*W]. */
+int pswin_window_map(int mode, int H, int W, int shift, int32_t* map, int32_t* inv, void* stream);
+
+/* Planar shifted-window attention mask, BasicLayer._get_attention_mask (HOT:664-688):
+ * mask[w][i][j] = 0 if tokens i, j of window w lie in the same of the 9 shift regions else -100.0.
+ * mask: f32 [n_windows, 49, 49] for the planar grid of (H, W). */
+int pswin_planar_mask(int H, int W, int shift, float* mask, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Geometry (fp32)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* make_uv_hw2 (HOT:153-189): uv[(y*W+x)*2 + {0,1}] = (u, v), u = x*gap - pi + gap/2, v = y*gap - pi/2 + gap/2,
+ * gap = pi/H, evaluated in fp32 in exactly that order (no FMA contraction) -> bit-identical to the reference. */
+int pswin_uv_grid(int H, int W, float* uv, void* stream);
+
+/* SimplePanoSwinTransformer._pano_abs_position input features (HOT:926-932):
+ * feat[t*5 + 0..4] = (sin u sin v, cos u sin v, cos v, u, v) for n tokens. */
+int pswin_abs_pos_features(const float* uv, int n, float* feat, void* stream);
+
+/* uv of every window slot: uv_win[slot] = uv[map[slot]] or (0, 0) in padding slots (the reference carries
+ * uv as two feature channels, so zero padding zeroes them: HOT:504-513). */
+int pswin_gather_uv(const float* uv, const int32_t* map, int n_slots, float* uv_win, void* stream);
+
+/* haversine22 (lzx/models/great_circle.py:71-86) per window:
+ * dist[w][i][j] = 2 asin(sqrt(sin^2(|v2_j - v1_i|/2) + cos v2_j cos v1_i sin^2((u2_j - u1_i)/2))).
+ * uv1, uv2: f32 [n_windows, 49, 2]; dist: f32 [n_windows, 49, 49]. */
+int pswin_haversine_windows(const float* uv1, const float* uv2, int n_windows, float* dist, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Row movers (HBM-bound gathers; the copies of window_partition / window_reverse / roll / flip / cat /
+ * pad that the reference materialises one by one: SURVEY appendix B)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* win[b][slot][:] = map[slot] >= 0 ? (scale ? scale[b] : 1) * x[b][map[slot]][:] : 0
+ * Forward of window partition (x = LayerNorm-ed features) and, with map = the forward map and scale = the
+ * per-sample DropPath factor, backward of pswin_window_scatter_add.
+ * x: [B, S, C] of x_dtype; win: [B, n_slots, C] of win_dtype; C % 8 == 0. */
+int pswin_window_gather(const void* x, int x_dtype, const int32_t* map, const float* scale, void* win,
+                        int win_dtype, int B, int S, int n_slots, int C, void* stream);
+
+/* out[b][t][:] = (resid ? resid[b][t][:] : 0) + (scale ? scale[b] : 1) * win[b][inv[t]][:]
+ * window_reverse + crop + reverse transition + residual add + DropPath scaling (HOT:483, 516-533), and,
+ * with resid = NULL, backward of pswin_window_gather.
+ * win: [B, n_slots, C] win_dtype; resid, out: [B, S, C] of x_dtype. */
+int pswin_window_scatter_add(const void* win, int win_dtype, const int32_t* inv, const void* resid,
+                             const float* scale, void* out, int x_dtype, int B, int S, int n_slots, int C,
+                             void* stream);
+
+/* PatchMerging gather (HOT:560-573): out[b][i*W2+j][k*C + c] = x[b][(2i+dy_k)*W + 2j+dx_k][c] or 0 outside,
+ * (dy,dx)_k = (0,0),(1,0),(0,1),(1,1); H2 = ceil(H/2), W2 = ceil(W/2).  x: [B, H*W, C], out: [B, H2*W2, 4C]. */
+int pswin_patch_merge_gather(const void* x, int x_dtype, void* out, int out_dtype, int B, int H, int W, int C,
+                             void* stream);
+
+/* Its adjoint: dx[b][h*W+w][c] = dout[b][(h/2)*W2 + w/2][((h&1) + 2*(w&1))*C + c]. */
+int pswin_patch_merge_scatter(const void* dout, int out_dtype, void* dx, int x_dtype, int B, int H, int W, int C,
+                              void* stream);
+
+/* Static 4-tap row interpolation (the two F.grid_sample calls of PitchAttentionModule.get_rotated,
+ * HOT:1038, 1090, with input-independent grids; lzx/pano_rotate.py:169-187):
+ * out[b][p][:] = sum_k wgt[p][k] * x[b][idx[p][k]][:]   x: [B, S, C] f32, out: [B, P, C] f32,
+ * idx: int32 [P, 4], wgt: f32 [P, 4]. */
+int pswin_interp_rows(const float* x, const int32_t* idx, const float* wgt, float* out, int B, int S, int P, int C,
+                      void* stream);
+
+/* Its adjoint (atomic f32 adds): dx[b][idx[p][k]][:] += wgt[p][k] * dout[b][p][:]; dx must be zeroed by the
+ * caller. */
+int pswin_interp_rows_adjoint(const float* dout, const int32_t* idx, const float* wgt, float* dx, int B, int S,
+                              int P, int C, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Window attention (the hot kernel): BasicWindowAttention.forward (HOT:274-311) between the qkv and
+ * proj Linear layers, and PitchAttentionModule._attention (HOT:1206-1237) between q/k/v_linear and proj.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* Additive score bias, shared by every image of the batch (BasicWindowAttention._sphere_bias, HOT:241-272,
+ * plus the shifted-window mask add of HOT:295-303), laid out as MFMA accumulator tiles:
+ *   bias(wb,h,i,j) = (dist ? dist[wb % n_dist][i][j] * alpha[idx(i,j)][h] : 0) + beta[idx(i,j)][h]
+ *                    + (mask ? mask[wb % n_mask][i][j] : 0)            for i, j < 49
+ *   idx(i,j) = (i/7 - j/7 + 6) * 13 + (i%7 - j%7 + 6)   (make_relative_position_index, HOT:95-129)
+ *   bias(.,.,i,j>=49) = -inf (padded keys never receive weight), bias(.,.,i>=49,j<49) = 0.
+ * bias_ij: f32 [n_bias_windows, heads, 64(i), 64(j)]; bias_ji: the same values transposed to [.., 64(j), 64(i)]
+ * (consumed by the backward kernel), may be NULL.
+ * dist: f32 [n_dist, 49, 49] or NULL (planar mode); alpha: f32 [169, heads] (ignored when dist is NULL);
+ * beta: f32 [169, heads]; mask: f32 [n_mask, 49, 49] or NULL.
+ * n_bias_windows must be a multiple of n_dist and of n_mask. */
+int pswin_attn_bias_build(const float* dist, int n_dist, const float* alpha, const float* beta, const float* mask,
+                          int n_mask, int n_bias_windows, int heads, float* bias_ij, float* bias_ji,
+                          void* stream);
+
+/* out[n][i][h*32 + d] = sum_j softmax_j(scale * q[n][i][h][:] . k[n][j][h][:] + bias(n % nb, h, i, j)) v[n][j][h][d]
+ * q, k, v: element pointers to head 0 of token 0 of window 0; token rows are ld_qkv elements apart, heads 32
+ * elements apart (one fused [n*49, 3C] qkv buffer: q = base, k = base + C, v = base + 2C, ld_qkv = 3C).
+ * out: [n_windows*49, ld_out]; lse: f32 [n_windows, heads, 64] = log-sum-exp of every score row (+inf in rows
+ * >= 49), kept for the backward pass.  n_windows % n_bias_windows == 0, window n uses bias tile n % n_bias_windows.
+ * dtype: q, k, v, out all PSWIN_F32 (exact-f32 MFMA) or all PSWIN_BF16 (bf16 MFMA, f32 softmax/accumulate).
+ * Pointers 16-byte aligned, ld_qkv % 8 == 0, ld_out % 8 == 0. */
+int pswin_attn_fwd(const void* q, const void* k, const void* v, int ld_qkv, const float* bias_ij, void* out,
+                   int ld_out, float* lse, int n_windows, int n_bias_windows, int heads, float scale, int dtype,
+                   void* stream);
+
+/* Gradients of pswin_attn_fwd.  dq, dk, dv use the q/k/v addressing (ld_dqkv), dout the out addressing.
+ * dbias_ji: f32 [n_chunks, n_bias_windows, heads, 64(j), 64(i)] receives, per chunk of the batch loop, the sum
+ * over that chunk's windows of dScore (the gradient w.r.t. bias, transposed like bias_ji); n_chunks is chosen by
+ * the caller (1 <= n_chunks <= n_windows / n_bias_windows, must divide it).  May be NULL when the bias needs no
+ * gradient (n_chunks is still used to split the batch loop). */
+int pswin_attn_bwd(const void* q, const void* k, const void* v, int ld_qkv, const float* bias_ji, const void* dout,
+                   int ld_out, const float* lse, void* dq, void* dk, void* dv, int ld_dqkv, float* dbias_ji,
+                   int n_chunks, int n_windows, int n_bias_windows, int heads, float scale, int dtype, void* stream);
+
+/* Host helper: the number of batch-loop chunks pswin_attn_fwd uses internally for this geometry (enough
+ * independent waves to fill the chip while keeping the per-tile bias reuse long); a good n_chunks for
+ * pswin_attn_bwd.  Returns the chunk count (>= 1) or PSWIN_ERR_ARG. */
+int pswin_attn_suggest_chunks(int n_windows, int n_bias_windows, int heads);
+
+/* Reduce dbias_ji tiles into the table gradients (adjoint of pswin_attn_bias_build w.r.t. alpha, beta):
+ *   dbeta[t][h]  = sum over tiles, (i,j) with idx(i,j) = t of g ;  dalpha[t][h] = the same sum of g * dist.
+ * dbias_ji: f32 [n_tiles, heads, 64, 64] with tile x belonging to bias window x % n_bias_windows;
+ * dalpha (may be NULL when dist is NULL), dbeta: f32 [169, heads], overwritten.
+ * workspace: f32, at least pswin_attn_bias_bwd_workspace(heads) elements. */
+int pswin_attn_bias_bwd_workspace(int heads);
+int pswin_attn_bias_bwd(const float* dbias_ji, int n_tiles, int n_bias_windows, const float* dist, int n_dist,
+                        int heads, float* dalpha, float* dbeta, float* workspace, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSWIN_H_ */

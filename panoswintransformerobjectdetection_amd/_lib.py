@@ -1,0 +1,112 @@
+"""ctypes binding of libpswin_hip.so (include/pswin.h).  There is no fallback: if the library is missing
+or a call fails, this raises.  PyTorch is used only for device memory and the current HIP stream."""
+import ctypes
+import os
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libpswin_hip.so")
+
+F32, BF16 = 0, 1
+MODE_PLANAR, MODE_PANO = 0, 1
+WS, WTOK, WPAD, HEAD_DIM = 7, 49, 64, 32
+ABI_VERSION = 1
+
+_vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+_ip = ctypes.POINTER(ctypes.c_int)
+
+# name -> argtypes; every function returns int.  Mirrors include/pswin.h one to one.
+_PROTOTYPES = {
+    "pswin_version": [],
+    "pswin_window_grid": [_i, _i, _i, _ip, _ip, _ip],
+    "pswin_window_map": [_i, _i, _i, _i, _vp, _vp, _vp],
+    "pswin_planar_mask": [_i, _i, _i, _vp, _vp],
+    "pswin_uv_grid": [_i, _i, _vp, _vp],
+    "pswin_abs_pos_features": [_vp, _i, _vp, _vp],
+    "pswin_gather_uv": [_vp, _vp, _i, _vp, _vp],
+    "pswin_haversine_windows": [_vp, _vp, _i, _vp, _vp],
+    "pswin_window_gather": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "pswin_window_scatter_add": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "pswin_patch_merge_gather": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
+    "pswin_patch_merge_scatter": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
+    "pswin_interp_rows": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "pswin_interp_rows_adjoint": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "pswin_attn_bias_build": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
+    "pswin_attn_fwd": [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _f, _i, _vp],
+    "pswin_attn_bwd": [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _i, _vp],
+    "pswin_attn_suggest_chunks": [_i, _i, _i],
+    "pswin_attn_bias_bwd_workspace": [_i],
+    "pswin_attn_bias_bwd": [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp],
+}
+
+_lib = None
+
+
+class PswinError(RuntimeError):
+    pass
+
+
+def exported_symbols():
+    return sorted(_PROTOTYPES)
+
+
+def load():
+    """Load the library once; raise loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise PswinError(
+            f"{LIB_PATH} is missing: build it with `python -m panoswintransformerobjectdetection_amd.build` "
+            "(hipcc, gfx950).  This package has no CPU or PyTorch fallback for its kernels.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in _PROTOTYPES.items():
+        fn = getattr(lib, name)          # AttributeError if the .so does not export a declared symbol
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    v = lib.pswin_version()
+    if v != ABI_VERSION:
+        raise PswinError(f"libpswin_hip.so ABI {v} != expected {ABI_VERSION}; rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        kind = {-1: "invalid argument", -2: "unsupported configuration"}.get(rc, f"hipError_t {rc}")
+        raise PswinError(f"{what} failed: {kind}")
+
+
+def dtype_code(t):
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise PswinError(f"unsupported dtype {t.dtype}: the kernels take float32 or bfloat16")
+
+
+def ptr(t):
+    if t is None:
+        return None
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def stream_of(t):
+    if not t.is_cuda:
+        raise PswinError("the PanoSwin kernels run on an MI355X (HIP) device only; got a CPU tensor")
+    return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def call(name, ref_tensor, *args):
+    """Invoke an entry point on the current stream of ref_tensor's device and raise on a non-zero status."""
+    lib = load()
+    with torch.cuda.device(ref_tensor.device):
+        rc = getattr(lib, name)(*args, stream_of(ref_tensor))
+    check(rc, name)
+
+
+def window_grid(mode, H, W):
+    hp, wp, nw = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+    check(load().pswin_window_grid(mode, H, W, ctypes.byref(hp), ctypes.byref(wp), ctypes.byref(nw)), "pswin_window_grid")
+    return hp.value, wp.value, nw.value

@@ -1,0 +1,372 @@
+"""SimplePanoSwinTransformer on MI355X: the reference backbone's interface over hand-written gfx950 kernels.
+
+Drop-in boundary (reference: mmdet/models/backbones/simple_panoswin_transformer.py = HOT):
+  * registry name ``SimplePanoSwinTransformer`` in mmdet's ``BACKBONES`` (HOT:779), same constructor kwargs and
+    defaults (HOT:781-801), ``init_weights(pretrained)``, ``forward(x, pano_ratio_v=None) -> tuple of NCHW fp32
+    maps`` (HOT:940-979), ``set_pano_mode`` / ``switch_pano_mode`` (HOT:192-208, 880-883), ``train(mode)``;
+  * identical ``state_dict`` keys and shapes, so reference checkpoints load with ``strict=True``.
+
+What runs where: every data-layout step of a block (LayerNorm-ed features -> pano/planar shift -> pad -> window
+partition, and the way back with crop, DropPath and the residual add) is one indexed row-copy kernel; the
+7x7 attention core (q.k^T, great-circle + relative-position bias, mask, softmax, .v) is one MFMA kernel per
+direction; PatchMerging's gather and the pitch module's two static bilinear resamplings are row kernels too
+(include/pswin.h).  Dense projections (qkv / proj / MLP / reduction), LayerNorm, GELU and the PatchEmbed
+convolutions go through PyTorch-ROCm (hipBLASLt / MIOpen).  uv coordinates never ride as feature channels
+(the reference's C+2 layout, HOT:964): they are a function of position, so the great-circle tables are cached
+per shape.
+
+Unsupported on purpose (raises, never falls back): CPU tensors, window_size != 7, head_dim != 32,
+drop_rate / attn_drop_rate != 0 (every reference config sets them to 0), norm_layer other than LayerNorm.
+"""
+import math
+import warnings
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+import torch.utils.checkpoint as checkpoint
+
+from . import geometry, ops
+from ._lib import HEAD_DIM, WS, WTOK, PswinError
+from .registry import BACKBONES
+
+
+def _relative_position_index(ws):
+    """make_relative_position_index (HOT:95-129); kept as a buffer only for state-dict compatibility."""
+    t = torch.arange(ws * ws)
+    hi, wi = t // ws, t % ws
+    return (hi[:, None] - hi[None, :] + ws - 1) * (2 * ws - 1) + (wi[:, None] - wi[None, :] + ws - 1)
+
+
+def _make_tables(ws, heads):
+    """make_table (HOT:132-150).  The reference's two Parameters alias one tensor on CPU and become
+    independent after ``.cuda()``; here they are independent parameters with identical initial values."""
+    a = nn.Parameter(torch.zeros((2 * ws - 1) ** 2, heads))
+    nn.init.trunc_normal_(a, std=.02, a=-2.0, b=2.0)
+    b = nn.Parameter(a.detach().clone())
+    return a, b
+
+
+def _drop_path_scale(x, p, training):
+    """Per-sample DropPath factor of timm's DropPath: floor(keep + U[0,1)) / keep, or None."""
+    if p == 0.0 or not training:
+        return None
+    keep = 1.0 - p
+    return torch.floor(keep + torch.rand(x.shape[0], dtype=torch.float32, device=x.device)) / keep
+
+
+class DoubleModeModule(object):
+    """HOT:192-208."""
+
+    def set_pano_mode(self, pano_mode: bool):
+        self.pano_mode = pano_mode
+
+    def switch_pano_mode(self):
+        self.set_pano_mode(not self.pano_mode)
+
+
+class Mlp(nn.Module):
+    """HOT:44-61."""
+
+    def __init__(self, in_features, hidden_features):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.fc2 = nn.Linear(hidden_features, in_features)
+
+    def forward(self, x, cd):
+        x = F.gelu(F.linear(x.to(cd), self.fc1.weight.to(cd), self.fc1.bias.to(cd)))
+        return F.linear(x, self.fc2.weight.to(cd), self.fc2.bias.to(cd))
+
+
+class WindowAttention(nn.Module, DoubleModeModule):
+    """Parameter holder of BasicWindowAttention / WindowAttention (HOT:211-323)."""
+
+    def __init__(self, dim, window_size, num_heads, qkv_bias=True, qk_scale=None, separate_qkv=False):
+        super().__init__()
+        if dim % num_heads or dim // num_heads != HEAD_DIM:
+            raise PswinError(f"the MI355X attention kernel is specialised for head_dim == {HEAD_DIM}, got dim={dim}, "
+                             f"heads={num_heads}")
+        self.dim, self.num_heads = dim, num_heads
+        self.scale = qk_scale or (dim // num_heads) ** -0.5
+        self.register_buffer("relative_position_index_OO", _relative_position_index(window_size))
+        self.proj = nn.Linear(dim, dim)
+        self.sphere_position_alpha_table_Te, self.sphere_position_beta_table_Te = _make_tables(window_size, num_heads)
+        if not separate_qkv:
+            self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+
+
+def _linear(x, lin, cd):
+    return F.linear(x.to(cd), lin.weight.to(cd), None if lin.bias is None else lin.bias.to(cd))
+
+
+class PanoSwinTransformerBlock(nn.Module, DoubleModeModule):
+    """HOT:412-536."""
+
+    def __init__(self, dim, num_heads, window_size=7, shift_size=0, mlp_ratio=4., qkv_bias=True, qk_scale=None,
+                 drop_path=0., pano_mode=True):
+        super().__init__()
+        assert 0 <= shift_size < window_size, "shift_size must in 0-window_size"
+        self.dim, self.num_heads, self.shift_size, self.drop_path_p = dim, num_heads, shift_size, float(drop_path)
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn = WindowAttention(dim, window_size, num_heads, qkv_bias, qk_scale)
+        self.norm2 = nn.LayerNorm(dim)
+        self.mlp = Mlp(dim, int(dim * mlp_ratio))
+        self.pano_mode = pano_mode
+
+    def forward(self, x, H, W, cd):
+        B, S, C = x.shape
+        assert S == H * W, "input feature has wrong size"
+        dev = x.device
+        pano = bool(self.pano_mode)
+        wmap, inv, nW = ops.window_maps(pano, H, W, self.shift_size, dev)
+        if pano:
+            dist, mask = ops.window_dist(H, W, self.shift_size, dev), None       # no mask in pano mode (HOT:698-699)
+        else:
+            dist = None
+            mask = ops.planar_mask(H, W, self.shift_size, dev) if self.shift_size else None   # HOT:474
+        a = self.attn
+        xn = F.layer_norm(x, (C,), self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        win = ops.window_gather(xn, wmap, inv, cd)                                # [B, nW*49, C]
+        qkv = _linear(win.view(-1, C), a.qkv, cd)                                 # [B*nW*49, 3C]
+        att = ops.window_attention(qkv, a.sphere_position_alpha_table_Te, a.sphere_position_beta_table_Te, dist, mask,
+                                   a.num_heads, a.scale, nW)
+        att = _linear(att, a.proj, cd).view(B, nW * WTOK, C)
+        scale = _drop_path_scale(x, self.drop_path_p, self.training)
+        x = ops.window_scatter_add(att, x, wmap, inv, scale)                      # shortcut + DropPath(attn)
+        y = self.mlp(F.layer_norm(x, (C,), self.norm2.weight, self.norm2.bias, self.norm2.eps), cd)
+        if scale is not None:
+            y = y * scale.to(y.dtype)[:, None, None]
+        return x + y.to(x.dtype)
+
+
+class PitchAttentionModule(WindowAttention):
+    """HOT:990-1237; appended to a stage whose depth is odd (HOT:636-647)."""
+
+    def __init__(self, dim, num_heads, window_size=7, qkv_bias=True, qk_scale=None, mlp_ratio=4., np_v=-0.0001,
+                 pano_mode=True):
+        super().__init__(dim, window_size, num_heads, qkv_bias, qk_scale, separate_qkv=True)
+        self.window_size = window_size
+        self.mlp = Mlp(dim, int(dim * mlp_ratio))
+        self.norm2 = nn.LayerNorm(dim)
+        self.norm1 = nn.LayerNorm(dim)
+        self.q_linear = nn.Linear(dim, dim, bias=qkv_bias)
+        self.k_linear = nn.Linear(dim, dim, bias=qkv_bias)
+        self.v_linear = nn.Linear(dim, dim, bias=qkv_bias)
+        self.register_buffer("np_uv", torch.Tensor([1.0, np_v]) * math.pi)
+        self.pano_mode = pano_mode
+        self._static = {}
+
+    def _tables(self, H, W, dev):
+        """Static resampling tables, the rotated-window uv and the q-vs-rotated-k distance table (per shape)."""
+        key = (H, W, str(dev))
+        if key not in self._static:
+            t = geometry.pitch_tables(H, W, self.window_size, self.np_uv)
+            t = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in t.items()}
+            wmap, _, nW = ops.window_maps(False, H, W, 0, dev)
+            uv = ops.uv_grid(H, W, dev)
+            uv4 = torch.cat([uv, torch.zeros_like(uv)], -1)[None].contiguous()           # rows of 4 for the row kernel
+            uv_rot = ops.interp_rows(ops.interp_rows(uv4, t["idx1"], t["w1"]), t["idx2"], t["w2"])[0, :, :2]
+            uv_win = ops.gather_uv(uv, wmap)
+            t["dist"] = ops.haversine_windows(uv_win.view(nW, WTOK, 2), uv_rot.contiguous().view(nW, WTOK, 2))
+            self._static[key] = t
+        return self._static[key]
+
+    def forward(self, x, H, W, cd):
+        B, S, C = x.shape
+        assert S == H * W, "input feature has wrong size"
+        dev = x.device
+        pano = bool(self.pano_mode)
+        wmap, inv, nW = ops.window_maps(False, H, W, 0, dev)
+        xn = F.layer_norm(x, (C,), self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        win = ops.window_gather(xn, wmap, inv, cd).view(-1, C)
+        if pano:
+            t = self._tables(H, W, dev)
+            rot = ops.interp_rows(ops.interp_rows(xn, t["idx1"], t["w1"]), t["idx2"], t["w2"])   # [B, nW*49, C]
+            win_rot, dist = rot.view(-1, C), t["dist"]
+        else:
+            win_rot, dist = win, None
+        q, k, v = _linear(win, self.q_linear, cd), _linear(win_rot, self.k_linear, cd), _linear(win, self.v_linear, cd)
+        att = ops.window_attention(q, self.sphere_position_alpha_table_Te, self.sphere_position_beta_table_Te, dist,
+                                   None, self.num_heads, self.scale, nW, k=k, v=v)
+        att = _linear(att, self.proj, cd).view(B, nW * WTOK, C)
+        # the reference overwrites its own shortcut with LN(x) (in-place norm on a view, HOT:1154-1155): residual = xn
+        x = ops.window_scatter_add(att, xn, wmap, inv, None)
+        y = self.mlp(F.layer_norm(x, (C,), self.norm2.weight, self.norm2.bias, self.norm2.eps), cd)
+        return x + y.to(x.dtype)
+
+
+class PatchMerging(nn.Module):
+    """HOT:539-576."""
+
+    def __init__(self, dim):
+        super().__init__()
+        self.dim = dim
+        self.reduction = nn.Linear(4 * dim, 2 * dim, bias=False)
+        self.norm = nn.LayerNorm(4 * dim)
+
+    def forward(self, x, H, W, cd):
+        B, S, C = x.shape
+        assert S == H * W, "input feature has wrong size"
+        g = ops.patch_merge_gather(x, H, W)
+        g = F.layer_norm(g, (4 * C,), self.norm.weight, self.norm.bias, self.norm.eps)
+        return _linear(g, self.reduction, cd).to(x.dtype)
+
+
+class BasicLayer(nn.Module, DoubleModeModule):
+    """HOT:579-724."""
+
+    def __init__(self, dim, depth, num_heads, window_size=7, mlp_ratio=4., qkv_bias=True, qk_scale=None,
+                 drop_path=0., downsample=None, use_checkpoint=False, pano_mode=True):
+        super().__init__()
+        self.use_checkpoint = use_checkpoint
+        blocks = [PanoSwinTransformerBlock(dim, num_heads, window_size, 0 if i % 2 == 0 else window_size // 2,
+                                           mlp_ratio, qkv_bias, qk_scale,
+                                           drop_path[i] if isinstance(drop_path, list) else drop_path, pano_mode)
+                  for i in range(depth - depth % 2)]
+        if depth % 2:
+            blocks.append(PitchAttentionModule(dim, num_heads, window_size, qkv_bias, qk_scale, mlp_ratio,
+                                               pano_mode=pano_mode))
+        self.blocks = nn.ModuleList(blocks)
+        self.downsample = downsample(dim) if downsample is not None else None
+        self.pano_mode = pano_mode
+
+    def set_pano_mode(self, pano_mode=True):
+        self.pano_mode = pano_mode
+        for blk in self.blocks:
+            blk.set_pano_mode(pano_mode)
+
+    def forward(self, x, H, W, cd):
+        for blk in self.blocks:
+            if self.use_checkpoint:
+                x = checkpoint.checkpoint(blk, x, H, W, cd, use_reentrant=False)
+            else:
+                x = blk(x, H, W, cd)
+        if self.downsample is None:
+            return x, H, W, x, H, W
+        return x, H, W, self.downsample(x, H, W, cd), (H + 1) // 2, (W + 1) // 2
+
+
+class PatchEmbed(nn.Module):
+    """HOT:727-773 (convolutions through MIOpen; channels-last so that the token layout needs no transpose)."""
+
+    def __init__(self, patch_size=4, in_chans=3, embed_dim=96, norm=True):
+        super().__init__()
+        self.patch_size = (patch_size, patch_size) if isinstance(patch_size, int) else tuple(patch_size)
+        self.embed_dim = embed_dim
+        c = embed_dim // 3
+        self.proj = nn.Sequential(
+            nn.Conv2d(in_chans, c, kernel_size=3, stride=1, padding=1), nn.BatchNorm2d(c), nn.ReLU(inplace=True),
+            nn.Conv2d(c, c * 2, kernel_size=3, stride=1, padding=1), nn.BatchNorm2d(c * 2), nn.ReLU(inplace=True),
+            nn.Conv2d(c * 2, embed_dim, kernel_size=self.patch_size, stride=self.patch_size))
+        self.norm = nn.LayerNorm(embed_dim) if norm else None
+
+    def forward(self, x):
+        _, _, H, W = x.shape
+        ph, pw = self.patch_size
+        if W % pw:
+            x = F.pad(x, (0, pw - W % pw))
+        if H % ph:
+            x = F.pad(x, (0, 0, 0, ph - H % ph))
+        x = self.proj(x.contiguous(memory_format=torch.channels_last))
+        B, C, Wh, Ww = x.shape
+        tok = x.permute(0, 2, 3, 1).reshape(B, Wh * Ww, C)         # free for a channels-last tensor
+        if self.norm is not None:
+            tok = F.layer_norm(tok, (C,), self.norm.weight, self.norm.bias, self.norm.eps)
+        return tok, Wh, Ww
+
+
+@BACKBONES.register_module()
+class SimplePanoSwinTransformer(nn.Module, DoubleModeModule):
+    """PanoSwin backbone (HOT:779-983) with the reference's constructor, plus one keyword:
+
+    compute_dtype: torch.float32 (default: fp32 end to end, the parity configuration) or torch.bfloat16 (bf16
+    GEMM / attention operands with fp32 accumulation, softmax, LayerNorm statistics and residual stream - the
+    analogue of the reference's apex O1 setting, mmdet/apis/train.py:82-88).
+    """
+
+    def __init__(self, patch_size=4, in_chans=3, embed_dim=96, depths=[2, 2, 7, 2], num_heads=[3, 6, 12, 24],
+                 window_size=7, mlp_ratio=4., qkv_bias=True, qk_scale=None, drop_rate=0., attn_drop_rate=0.,
+                 drop_path_rate=0.2, norm_layer=nn.LayerNorm, ape=False, patch_norm=True, out_indices=(0, 1, 2, 3),
+                 frozen_stages=-1, use_checkpoint=False, pano_mode=True, compute_dtype=torch.float32):
+        super().__init__()
+        if window_size != WS:
+            raise PswinError(f"the MI355X kernels are specialised for window_size == {WS}, got {window_size}")
+        if drop_rate != 0. or attn_drop_rate != 0.:
+            raise PswinError("drop_rate / attn_drop_rate must be 0 (as in every reference config); only DropPath is "
+                             "implemented")
+        if norm_layer is not nn.LayerNorm and norm_layer != "LN" and norm_layer is not None:
+            raise PswinError("norm_layer must be nn.LayerNorm")
+        if isinstance(compute_dtype, str):
+            compute_dtype = {"float32": torch.float32, "fp32": torch.float32, "bfloat16": torch.bfloat16,
+                             "bf16": torch.bfloat16}[compute_dtype]
+        if compute_dtype not in (torch.float32, torch.bfloat16):
+            raise PswinError("compute_dtype must be float32 or bfloat16")
+        self.compute_dtype = compute_dtype
+        self.num_layers, self.embed_dim, self.ape, self.patch_norm = len(depths), embed_dim, ape, patch_norm
+        self.out_indices, self.frozen_stages = out_indices, frozen_stages      # frozen_stages is ignored, as in HOT:833
+        self.patch_embed = PatchEmbed(patch_size, in_chans, embed_dim, patch_norm)
+        if self.ape:
+            self.abs_encoder = nn.Linear(5, embed_dim)
+        dpr = [v.item() for v in torch.linspace(0, drop_path_rate, sum(depths))]
+        self.layers = nn.ModuleList()
+        for i in range(self.num_layers):
+            self.layers.append(BasicLayer(int(embed_dim * 2 ** i), depths[i], num_heads[i], window_size, mlp_ratio,
+                                          qkv_bias, qk_scale, dpr[sum(depths[:i]):sum(depths[:i + 1])],
+                                          PatchMerging if i < self.num_layers - 1 else None, use_checkpoint,
+                                          pano_mode))
+        self.num_features = [int(embed_dim * 2 ** i) for i in range(self.num_layers)]
+        for i in out_indices:
+            self.add_module(f"norm{i}", nn.LayerNorm(self.num_features[i]))
+        self.set_pano_mode(pano_mode)
+
+    def set_pano_mode(self, pano_mode=True):
+        self.pano_mode = pano_mode
+        for layer in self.layers:
+            layer.set_pano_mode(pano_mode)
+
+    def init_weights(self, pretrained=None):
+        """HOT:885-907."""
+        def _init_weights(m):
+            if isinstance(m, nn.Linear):
+                nn.init.trunc_normal_(m.weight, std=.02, a=-2.0, b=2.0)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+            elif isinstance(m, nn.LayerNorm):
+                nn.init.constant_(m.bias, 0)
+                nn.init.constant_(m.weight, 1.0)
+
+        if isinstance(pretrained, str):
+            self.apply(_init_weights)
+            from .checkpoint import load_checkpoint
+            load_checkpoint(self, pretrained, strict=False)
+        elif pretrained is None:
+            self.apply(_init_weights)
+        else:
+            raise TypeError('pretrained must be a str or None')
+
+    def forward(self, x_bchw, pano_ratio_v=None):
+        if pano_ratio_v is not None:
+            warnings.warn("Parameter pano_ratio_v for is deprecated! Please set it to None!")
+        if self.pano_mode and x_bchw.shape[3] != x_bchw.shape[2] * 2:
+            warnings.warn("PanoSwin is configured in Pano mode, expecting channel3 == 2 * channel2, but get {} and {}, "
+                          "probably cause an error".format(x_bchw.shape[3], x_bchw.shape[2]))
+        if not x_bchw.is_cuda:
+            raise PswinError("SimplePanoSwinTransformer (MI355X build) needs its input on a HIP device")
+        cd = self.compute_dtype
+        x, Wh, Ww = self.patch_embed(x_bchw.float())
+        if self.pano_mode and self.ape:
+            feat = ops.abs_pos_features(Wh, Ww, x.device)                               # HOT:926-934
+            x = x + F.linear(feat, self.abs_encoder.weight, self.abs_encoder.bias)[None]
+        outs = []
+        for i, layer in enumerate(self.layers):
+            x_out, H, W, x, Wh, Ww = layer(x, Wh, Ww, cd)
+            if i in self.out_indices:
+                nl = getattr(self, f"norm{i}")
+                y = F.layer_norm(x_out, (self.num_features[i],), nl.weight, nl.bias, nl.eps)
+                outs.append(y.view(-1, H, W, self.num_features[i]).permute(0, 3, 1, 2).contiguous())
+        return tuple(outs)
+
+    def train(self, mode=True):
+        """The reference's train() forgets to return self (HOT:981-983); nn.Module semantics are kept here."""
+        super().train(mode)
+        return self

@@ -1,0 +1,71 @@
+// Shared device/host helpers for libpswin_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pswin.h"
+
+#define PSWIN_CHECK_ARG(cond) \
+    do {                      \
+        if (!(cond)) return PSWIN_ERR_ARG; \
+    } while (0)
+
+#define PSWIN_LAUNCH_RET()                              \
+    do {                                                \
+        hipError_t e__ = hipGetLastError();             \
+        return e__ == hipSuccess ? PSWIN_OK : (int)e__; \
+    } while (0)
+
+namespace pswin {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+__host__ __device__ inline int ceil_to(int v, int m) { return (v + m - 1) / m * m; }
+
+__device__ inline float bf16_bits_to_f32(unsigned short b) {
+    return __builtin_bit_cast(float, (unsigned int)b << 16);
+}
+// round-to-nearest-even f32 -> bf16 (hipcc lowers the cast to v_cvt_pk_bf16_f32 on gfx950, NaN-preserving)
+__device__ inline unsigned short f32_to_bf16_bits(float f) {
+    __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(unsigned short, b);
+}
+
+// 4 consecutive elements of a row, as f32, from an f32 or bf16 buffer
+template <int DT>
+__device__ inline f32x4 load4(const void* base, size_t elem_off) {
+    if constexpr (DT == PSWIN_F32) {
+        return *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(base) + elem_off);
+    } else {
+        u32x2 raw = *reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(base) + elem_off);
+        f32x4 r;
+        r[0] = __builtin_bit_cast(float, raw[0] << 16);
+        r[1] = __builtin_bit_cast(float, raw[0] & 0xffff0000u);
+        r[2] = __builtin_bit_cast(float, raw[1] << 16);
+        r[3] = __builtin_bit_cast(float, raw[1] & 0xffff0000u);
+        return r;
+    }
+}
+
+template <int DT>
+__device__ inline void store4(void* base, size_t elem_off, f32x4 v) {
+    if constexpr (DT == PSWIN_F32) {
+        *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + elem_off) = v;
+    } else {
+        u32x2 raw;
+        raw[0] = (unsigned int)f32_to_bf16_bits(v[0]) | ((unsigned int)f32_to_bf16_bits(v[1]) << 16);
+        raw[1] = (unsigned int)f32_to_bf16_bits(v[2]) | ((unsigned int)f32_to_bf16_bits(v[3]) << 16);
+        *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(base) + elem_off) = raw;
+    }
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+inline bool valid_dtype(int dt) { return dt == PSWIN_F32 || dt == PSWIN_BF16; }
+
+}  // namespace pswin

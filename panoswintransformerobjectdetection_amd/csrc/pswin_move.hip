@@ -1,0 +1,261 @@
+// Row movers: every data-layout step of a PanoSwin block as ONE indexed row copy.
+//
+// The reference materialises, per block, roll -> flip -> cat -> roll -> pad -> view/permute/contiguous on
+// the way in (WindowTransition.forward, pad_x, window_partition: HOT:393-406, 486-491, 64-75) and the
+// inverse chain plus the residual add on the way out (HOT:78-92, 516-533): ~12 full-tensor copies.  Here a
+// precomputed int32 window map (pswin_index.hip) turns each direction into a single HBM-bound gather of
+// C-element rows, fused with the dtype conversion, the DropPath per-sample scale and the residual add.
+// PatchMerging's strided 2x2 gather + concat (HOT:563-572) and the two static F.grid_sample calls of the
+// pitch module (HOT:1038, 1090) are the same kind of kernel.
+// HOT = mmdet/models/backbones/simple_panoswin_transformer.py of the reference.
+//
+// Thread mapping: a row of C elements is C/4 lanes x 4 elements (16 B f32 / 8 B bf16 per lane, consecutive
+// lanes on consecutive addresses); a 256-thread block covers 256/(C/4) rows.
+#include "pswin_common.hpp"
+
+using namespace pswin;
+
+namespace {
+
+struct RowGeom {
+    int vpr;   // 4-element vectors per row
+    dim3 block;
+    unsigned rows_per_block;
+};
+
+inline RowGeom row_geom(int C) {
+    RowGeom g;
+    g.vpr = C / 4;
+    unsigned bx = g.vpr < 256 ? g.vpr : 256;
+    unsigned by = 256 / bx;
+    if (by < 1) by = 1;
+    g.block = dim3(bx, by);
+    g.rows_per_block = by;
+    return g;
+}
+
+template <int XDT, int WDT>
+__global__ void window_gather_kernel(const void* __restrict__ x, const int32_t* __restrict__ map,
+                                     const float* __restrict__ scale, void* __restrict__ win, long long rows,
+                                     int S, int n_slots, int vpr) {
+    long long row = (long long)blockIdx.x * blockDim.y + threadIdx.y;
+    if (row >= rows) return;
+    int b = (int)(row / n_slots);
+    int slot = (int)(row - (long long)b * n_slots);
+    int src = map[slot];
+    float sc = scale ? scale[b] : 1.0f;
+    size_t C = (size_t)vpr * 4;
+    for (int v = threadIdx.x; v < vpr; v += blockDim.x) {
+        f32x4 val = {0.f, 0.f, 0.f, 0.f};
+        if (src >= 0) {
+            val = load4<XDT>(x, ((size_t)b * S + src) * C + 4 * (size_t)v);
+            if (scale) val = val * sc;
+        }
+        store4<WDT>(win, (size_t)row * C + 4 * (size_t)v, val);
+    }
+}
+
+template <int WDT, int XDT>
+__global__ void window_scatter_add_kernel(const void* __restrict__ win, const int32_t* __restrict__ inv,
+                                          const void* __restrict__ resid, const float* __restrict__ scale,
+                                          void* __restrict__ out, long long rows, int S, int n_slots, int vpr) {
+    long long row = (long long)blockIdx.x * blockDim.y + threadIdx.y;
+    if (row >= rows) return;
+    int b = (int)(row / S);
+    int t = (int)(row - (long long)b * S);
+    int slot = inv[t];
+    float sc = scale ? scale[b] : 1.0f;
+    size_t C = (size_t)vpr * 4;
+    for (int v = threadIdx.x; v < vpr; v += blockDim.x) {
+        f32x4 val = load4<WDT>(win, ((size_t)b * n_slots + slot) * C + 4 * (size_t)v);
+        if (scale) val = val * sc;
+        if (resid) val = val + load4<XDT>(resid, (size_t)row * C + 4 * (size_t)v);
+        store4<XDT>(out, (size_t)row * C + 4 * (size_t)v, val);
+    }
+}
+
+template <int XDT, int ODT>
+__global__ void patch_merge_gather_kernel(const void* __restrict__ x, void* __restrict__ out, long long rows, int H,
+                                          int W, int H2, int W2, int vpr) {
+    // one "row" = one C-wide quarter of a merged token: rows = B * H2 * W2 * 4
+    long long row = (long long)blockIdx.x * blockDim.y + threadIdx.y;
+    if (row >= rows) return;
+    int k = (int)(row & 3);
+    long long tok = row >> 2;
+    int b = (int)(tok / ((long long)H2 * W2));
+    int r = (int)(tok - (long long)b * H2 * W2);
+    int i = r / W2, j = r - i * W2;
+    int yy = 2 * i + (k & 1), xx = 2 * j + (k >> 1);   // blocks: (0,0), (1,0), (0,1), (1,1) = (dy, dx)
+    bool ok = yy < H && xx < W;
+    size_t C = (size_t)vpr * 4;
+    for (int v = threadIdx.x; v < vpr; v += blockDim.x) {
+        f32x4 val = {0.f, 0.f, 0.f, 0.f};
+        if (ok) val = load4<XDT>(x, ((size_t)b * H * W + (size_t)yy * W + xx) * C + 4 * (size_t)v);
+        store4<ODT>(out, (size_t)row * C + 4 * (size_t)v, val);
+    }
+}
+
+template <int ODT, int XDT>
+__global__ void patch_merge_scatter_kernel(const void* __restrict__ dout, void* __restrict__ dx, long long rows,
+                                           int H, int W, int H2, int W2, int vpr) {
+    long long row = (long long)blockIdx.x * blockDim.y + threadIdx.y;   // rows = B * H * W
+    if (row >= rows) return;
+    int b = (int)(row / ((long long)H * W));
+    int r = (int)(row - (long long)b * H * W);
+    int h = r / W, w = r - h * W;
+    int k = (h & 1) + 2 * (w & 1);
+    size_t C = (size_t)vpr * 4;
+    size_t src = (((size_t)b * H2 + (h >> 1)) * W2 + (w >> 1)) * 4 + k;
+    for (int v = threadIdx.x; v < vpr; v += blockDim.x) {
+        f32x4 val = load4<ODT>(dout, src * C + 4 * (size_t)v);
+        store4<XDT>(dx, (size_t)row * C + 4 * (size_t)v, val);
+    }
+}
+
+__global__ void interp_rows_kernel(const float* __restrict__ x, const int32_t* __restrict__ idx,
+                                   const float* __restrict__ wgt, float* __restrict__ out, long long rows, int S,
+                                   int P, int vpr) {
+    long long row = (long long)blockIdx.x * blockDim.y + threadIdx.y;
+    if (row >= rows) return;
+    int b = (int)(row / P);
+    int p = (int)(row - (long long)b * P);
+    size_t C = (size_t)vpr * 4;
+    int i0 = idx[4 * p], i1 = idx[4 * p + 1], i2 = idx[4 * p + 2], i3 = idx[4 * p + 3];
+    float w0 = wgt[4 * p], w1 = wgt[4 * p + 1], w2 = wgt[4 * p + 2], w3 = wgt[4 * p + 3];
+    const float* xb = x + (size_t)b * S * C;
+    for (int v = threadIdx.x; v < vpr; v += blockDim.x) {
+        // same accumulation order as ATen's bilinear grid_sample: nw, ne, sw, se
+        f32x4 a = *reinterpret_cast<const f32x4*>(xb + (size_t)i0 * C + 4 * v) * w0;
+        a = a + *reinterpret_cast<const f32x4*>(xb + (size_t)i1 * C + 4 * v) * w1;
+        a = a + *reinterpret_cast<const f32x4*>(xb + (size_t)i2 * C + 4 * v) * w2;
+        a = a + *reinterpret_cast<const f32x4*>(xb + (size_t)i3 * C + 4 * v) * w3;
+        *reinterpret_cast<f32x4*>(out + (size_t)row * C + 4 * (size_t)v) = a;
+    }
+}
+
+__global__ void interp_rows_adjoint_kernel(const float* __restrict__ dout, const int32_t* __restrict__ idx,
+                                           const float* __restrict__ wgt, float* __restrict__ dx, long long rows,
+                                           int S, int P, int vpr) {
+    long long row = (long long)blockIdx.x * blockDim.y + threadIdx.y;
+    if (row >= rows) return;
+    int b = (int)(row / P);
+    int p = (int)(row - (long long)b * P);
+    size_t C = (size_t)vpr * 4;
+    float* xb = dx + (size_t)b * S * C;
+    for (int v = threadIdx.x; v < vpr; v += blockDim.x) {
+        f32x4 g = *reinterpret_cast<const f32x4*>(dout + (size_t)row * C + 4 * (size_t)v);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float w = wgt[4 * p + k];
+            if (w == 0.f) continue;
+            float* dst = xb + (size_t)idx[4 * p + k] * C + 4 * v;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) atomicAdd(dst + c, g[c] * w);
+        }
+    }
+}
+
+template <typename F>
+inline int dispatch2(int a, int b, F&& f) {
+    if (a == PSWIN_F32 && b == PSWIN_F32) return f(std::integral_constant<int, PSWIN_F32>(), std::integral_constant<int, PSWIN_F32>());
+    if (a == PSWIN_F32 && b == PSWIN_BF16) return f(std::integral_constant<int, PSWIN_F32>(), std::integral_constant<int, PSWIN_BF16>());
+    if (a == PSWIN_BF16 && b == PSWIN_F32) return f(std::integral_constant<int, PSWIN_BF16>(), std::integral_constant<int, PSWIN_F32>());
+    return f(std::integral_constant<int, PSWIN_BF16>(), std::integral_constant<int, PSWIN_BF16>());
+}
+
+inline bool rows_ok(long long rows, unsigned rpb) { return rows > 0 && (rows + rpb - 1) / rpb < (1ll << 31); }
+
+}  // namespace
+
+extern "C" int pswin_window_gather(const void* x, int x_dtype, const int32_t* map, const float* scale, void* win,
+                                   int win_dtype, int B, int S, int n_slots, int C, void* stream) {
+    PSWIN_CHECK_ARG(x && map && win && B > 0 && S > 0 && n_slots > 0 && C > 0);
+    PSWIN_CHECK_ARG(valid_dtype(x_dtype) && valid_dtype(win_dtype));
+    PSWIN_CHECK_ARG(C % 8 == 0 && aligned16(x) && aligned16(win));
+    RowGeom g = row_geom(C);
+    long long rows = (long long)B * n_slots;
+    PSWIN_CHECK_ARG(rows_ok(rows, g.rows_per_block));
+    dim3 grid((unsigned)((rows + g.rows_per_block - 1) / g.rows_per_block));
+    return dispatch2(x_dtype, win_dtype, [&](auto xd, auto wd) {
+        hipLaunchKernelGGL((window_gather_kernel<decltype(xd)::value, decltype(wd)::value>), grid, g.block, 0,
+                           (hipStream_t)stream, x, map, scale, win, rows, S, n_slots, g.vpr);
+        PSWIN_LAUNCH_RET();
+    });
+}
+
+extern "C" int pswin_window_scatter_add(const void* win, int win_dtype, const int32_t* inv, const void* resid,
+                                        const float* scale, void* out, int x_dtype, int B, int S, int n_slots, int C,
+                                        void* stream) {
+    PSWIN_CHECK_ARG(win && inv && out && B > 0 && S > 0 && n_slots > 0 && C > 0);
+    PSWIN_CHECK_ARG(valid_dtype(x_dtype) && valid_dtype(win_dtype));
+    PSWIN_CHECK_ARG(C % 8 == 0 && aligned16(win) && aligned16(out) && aligned16(resid));
+    RowGeom g = row_geom(C);
+    long long rows = (long long)B * S;
+    PSWIN_CHECK_ARG(rows_ok(rows, g.rows_per_block));
+    dim3 grid((unsigned)((rows + g.rows_per_block - 1) / g.rows_per_block));
+    return dispatch2(win_dtype, x_dtype, [&](auto wd, auto xd) {
+        hipLaunchKernelGGL((window_scatter_add_kernel<decltype(wd)::value, decltype(xd)::value>), grid, g.block, 0,
+                           (hipStream_t)stream, win, inv, resid, scale, out, rows, S, n_slots, g.vpr);
+        PSWIN_LAUNCH_RET();
+    });
+}
+
+extern "C" int pswin_patch_merge_gather(const void* x, int x_dtype, void* out, int out_dtype, int B, int H, int W,
+                                        int C, void* stream) {
+    PSWIN_CHECK_ARG(x && out && B > 0 && H > 0 && W > 0 && C > 0);
+    PSWIN_CHECK_ARG(valid_dtype(x_dtype) && valid_dtype(out_dtype));
+    PSWIN_CHECK_ARG(C % 8 == 0 && aligned16(x) && aligned16(out));
+    RowGeom g = row_geom(C);
+    int H2 = (H + 1) / 2, W2 = (W + 1) / 2;
+    long long rows = (long long)B * H2 * W2 * 4;
+    PSWIN_CHECK_ARG(rows_ok(rows, g.rows_per_block));
+    dim3 grid((unsigned)((rows + g.rows_per_block - 1) / g.rows_per_block));
+    return dispatch2(x_dtype, out_dtype, [&](auto xd, auto od) {
+        hipLaunchKernelGGL((patch_merge_gather_kernel<decltype(xd)::value, decltype(od)::value>), grid, g.block, 0,
+                           (hipStream_t)stream, x, out, rows, H, W, H2, W2, g.vpr);
+        PSWIN_LAUNCH_RET();
+    });
+}
+
+extern "C" int pswin_patch_merge_scatter(const void* dout, int out_dtype, void* dx, int x_dtype, int B, int H, int W,
+                                         int C, void* stream) {
+    PSWIN_CHECK_ARG(dout && dx && B > 0 && H > 0 && W > 0 && C > 0);
+    PSWIN_CHECK_ARG(valid_dtype(x_dtype) && valid_dtype(out_dtype));
+    PSWIN_CHECK_ARG(C % 8 == 0 && aligned16(dout) && aligned16(dx));
+    RowGeom g = row_geom(C);
+    int H2 = (H + 1) / 2, W2 = (W + 1) / 2;
+    long long rows = (long long)B * H * W;
+    PSWIN_CHECK_ARG(rows_ok(rows, g.rows_per_block));
+    dim3 grid((unsigned)((rows + g.rows_per_block - 1) / g.rows_per_block));
+    return dispatch2(out_dtype, x_dtype, [&](auto od, auto xd) {
+        hipLaunchKernelGGL((patch_merge_scatter_kernel<decltype(od)::value, decltype(xd)::value>), grid, g.block, 0,
+                           (hipStream_t)stream, dout, dx, rows, H, W, H2, W2, g.vpr);
+        PSWIN_LAUNCH_RET();
+    });
+}
+
+extern "C" int pswin_interp_rows(const float* x, const int32_t* idx, const float* wgt, float* out, int B, int S,
+                                 int P, int C, void* stream) {
+    PSWIN_CHECK_ARG(x && idx && wgt && out && B > 0 && S > 0 && P > 0 && C > 0);
+    PSWIN_CHECK_ARG(C % 4 == 0 && aligned16(x) && aligned16(out));
+    RowGeom g = row_geom(C);
+    long long rows = (long long)B * P;
+    PSWIN_CHECK_ARG(rows_ok(rows, g.rows_per_block));
+    dim3 grid((unsigned)((rows + g.rows_per_block - 1) / g.rows_per_block));
+    hipLaunchKernelGGL(interp_rows_kernel, grid, g.block, 0, (hipStream_t)stream, x, idx, wgt, out, rows, S, P,
+                       g.vpr);
+    PSWIN_LAUNCH_RET();
+}
+
+extern "C" int pswin_interp_rows_adjoint(const float* dout, const int32_t* idx, const float* wgt, float* dx, int B,
+                                         int S, int P, int C, void* stream) {
+    PSWIN_CHECK_ARG(dout && idx && wgt && dx && B > 0 && S > 0 && P > 0 && C > 0);
+    PSWIN_CHECK_ARG(C % 4 == 0 && aligned16(dout) && aligned16(dx));
+    RowGeom g = row_geom(C);
+    long long rows = (long long)B * P;
+    PSWIN_CHECK_ARG(rows_ok(rows, g.rows_per_block));
+    dim3 grid((unsigned)((rows + g.rows_per_block - 1) / g.rows_per_block));
+    hipLaunchKernelGGL(interp_rows_adjoint_kernel, grid, g.block, 0, (hipStream_t)stream, dout, idx, wgt, dx, rows,
+                       S, P, g.vpr);
+    PSWIN_LAUNCH_RET();
+}

@@ -1,0 +1,307 @@
+"""Operators of the PanoSwin hot path: torch.autograd wrappers over the C-ABI kernels (include/pswin.h).
+
+Every function here launches hand-written gfx950 kernels from libpswin_hip.so on the current HIP stream.
+There is no PyTorch/CPU fallback: a CPU tensor or a missing library raises ``PswinError``.
+Reference file:line citations use HOT = mmdet/models/backbones/simple_panoswin_transformer.py.
+"""
+import math
+
+import torch
+
+from . import _lib
+from ._lib import BF16, F32, MODE_PANO, MODE_PLANAR, WPAD, WTOK, call, dtype_code, ptr
+
+_CACHE = {}
+
+
+def _dev_key(device):
+    device = torch.device(device)
+    return (device.type, device.index if device.index is not None else torch.cuda.current_device())
+
+
+def clear_caches():
+    _CACHE.clear()
+
+
+# ------------------------------------------------------------------------------------------------
+# static (input independent) tables, cached per feature-map shape and device
+# ------------------------------------------------------------------------------------------------
+def window_maps(pano, H, W, shift, device):
+    """(map int32 [nW*49], inv int32 [H*W], nW): WindowTransition + pad_x + window_partition as an index map
+    (HOT:376-409, 486-491, 64-75) and its inverse (HOT:78-92, 516-528)."""
+    key = ("map", bool(pano), H, W, shift, _dev_key(device))
+    if key not in _CACHE:
+        mode = MODE_PANO if pano else MODE_PLANAR
+        _, _, nW = _lib.window_grid(mode, H, W)
+        wmap = torch.empty(nW * WTOK, dtype=torch.int32, device=device)
+        inv = torch.empty(H * W, dtype=torch.int32, device=device)
+        call("pswin_window_map", wmap, mode, H, W, shift, ptr(wmap), ptr(inv))
+        _CACHE[key] = (wmap, inv, nW)
+    return _CACHE[key]
+
+
+def planar_mask(H, W, shift, device):
+    """BasicLayer._get_attention_mask (HOT:664-688): f32 [nW, 49, 49] of 0 / -100."""
+    key = ("mask", H, W, shift, _dev_key(device))
+    if key not in _CACHE:
+        _, _, nW = _lib.window_grid(MODE_PLANAR, H, W)
+        mask = torch.empty(nW, WTOK, WTOK, dtype=torch.float32, device=device)
+        call("pswin_planar_mask", mask, H, W, shift, ptr(mask))
+        _CACHE[key] = mask
+    return _CACHE[key]
+
+
+def uv_grid(H, W, device):
+    """make_uv_hw2 (HOT:153-189): f32 [H*W, 2]."""
+    key = ("uv", H, W, _dev_key(device))
+    if key not in _CACHE:
+        uv = torch.empty(H * W, 2, dtype=torch.float32, device=device)
+        call("pswin_uv_grid", uv, H, W, ptr(uv))
+        _CACHE[key] = uv
+    return _CACHE[key]
+
+
+def abs_pos_features(H, W, device):
+    """xyzuv features of _pano_abs_position (HOT:926-932): f32 [H*W, 5]."""
+    key = ("xyzuv", H, W, _dev_key(device))
+    if key not in _CACHE:
+        uv = uv_grid(H, W, device)
+        feat = torch.empty(H * W, 5, dtype=torch.float32, device=device)
+        call("pswin_abs_pos_features", feat, ptr(uv), H * W, ptr(feat))
+        _CACHE[key] = feat
+    return _CACHE[key]
+
+
+def gather_uv(uv, wmap):
+    out = torch.empty(wmap.numel(), 2, dtype=torch.float32, device=uv.device)
+    call("pswin_gather_uv", uv, ptr(uv), ptr(wmap), wmap.numel(), ptr(out))
+    return out
+
+
+def haversine_windows(uv1, uv2):
+    """haversine22 per window (lzx/models/great_circle.py:71-86): [n, 49, 2] x [n, 49, 2] -> [n, 49, 49]."""
+    uv1, uv2 = uv1.contiguous().float(), uv2.contiguous().float()
+    n = uv1.numel() // (2 * WTOK)
+    dist = torch.empty(n, WTOK, WTOK, dtype=torch.float32, device=uv1.device)
+    call("pswin_haversine_windows", dist, ptr(uv1), ptr(uv2), n, ptr(dist))
+    return dist
+
+
+def window_dist(H, W, shift, device):
+    """Great-circle distance table of a pano block: [nW, 49, 49], identical for every image and step."""
+    key = ("dist", H, W, shift, _dev_key(device))
+    if key not in _CACHE:
+        wmap, _, nW = window_maps(True, H, W, shift, device)
+        uvw = gather_uv(uv_grid(H, W, device), wmap).view(nW, WTOK, 2)
+        _CACHE[key] = haversine_windows(uvw, uvw)
+    return _CACHE[key]
+
+
+# ------------------------------------------------------------------------------------------------
+# row movers
+# ------------------------------------------------------------------------------------------------
+def _gather_raw(x, wmap, scale, n_slots, out_dtype):
+    B, S, C = x.shape
+    win = torch.empty(B, n_slots, C, dtype=out_dtype, device=x.device)
+    call("pswin_window_gather", x, ptr(x), dtype_code(x), ptr(wmap), ptr(scale), ptr(win), dtype_code(win), B, S,
+         n_slots, C)
+    return win
+
+
+def _scatter_raw(win, inv, resid, scale, S, out_dtype):
+    B, n_slots, C = win.shape
+    out = torch.empty(B, S, C, dtype=out_dtype, device=win.device)
+    call("pswin_window_scatter_add", win, ptr(win), dtype_code(win), ptr(inv), ptr(resid), ptr(scale), ptr(out),
+         dtype_code(out), B, S, n_slots, C)
+    return out
+
+
+class _WindowGather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, wmap, inv, out_dtype):
+        ctx.save_for_backward(inv)
+        ctx.S, ctx.in_dtype = x.shape[1], x.dtype
+        return _gather_raw(x.contiguous(), wmap, None, wmap.numel(), out_dtype)
+
+    @staticmethod
+    def backward(ctx, dwin):
+        (inv,) = ctx.saved_tensors
+        return _scatter_raw(dwin.contiguous(), inv, None, None, ctx.S, ctx.in_dtype), None, None, None
+
+
+def window_gather(x, wmap, inv, out_dtype=None):
+    """[B, S, C] -> [B, nW*49, C]: shift + pad + window partition in one indexed row copy."""
+    return _WindowGather.apply(x, wmap, inv, out_dtype or x.dtype)
+
+
+class _WindowScatterAdd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, win, resid, wmap, inv, scale):
+        ctx.save_for_backward(wmap, scale)
+        ctx.win_dtype = win.dtype
+        return _scatter_raw(win.contiguous(), inv, resid.contiguous(), scale, resid.shape[1], resid.dtype)
+
+    @staticmethod
+    def backward(ctx, dout):
+        wmap, scale = ctx.saved_tensors
+        dout = dout.contiguous()
+        dwin = _gather_raw(dout, wmap, scale, wmap.numel(), ctx.win_dtype)
+        return dwin, dout, None, None, None
+
+
+def window_scatter_add(win, resid, wmap, inv, scale=None):
+    """resid + scale_b * window_reverse(win): window reverse + crop + reverse shift + DropPath + residual
+    (HOT:483, 516-533) in one indexed row copy.  win [B, nW*49, C], resid [B, S, C]."""
+    return _WindowScatterAdd.apply(win, resid, wmap, inv, scale)
+
+
+class _PatchMergeGather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, H, W, out_dtype):
+        B, S, C = x.shape
+        ctx.geom = (B, H, W, C, x.dtype)
+        H2, W2 = (H + 1) // 2, (W + 1) // 2
+        x = x.contiguous()
+        out = torch.empty(B, H2 * W2, 4 * C, dtype=out_dtype, device=x.device)
+        call("pswin_patch_merge_gather", x, ptr(x), dtype_code(x), ptr(out), dtype_code(out), B, H, W, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, H, W, C, dt = ctx.geom
+        dout = dout.contiguous()
+        dx = torch.empty(B, H * W, C, dtype=dt, device=dout.device)
+        call("pswin_patch_merge_scatter", dout, ptr(dout), dtype_code(dout), ptr(dx), dtype_code(dx), B, H, W, C)
+        return dx, None, None, None
+
+
+def patch_merge_gather(x, H, W, out_dtype=None):
+    """PatchMerging's 2x2 strided gather + concat (HOT:560-573): [B, H*W, C] -> [B, ceil(H/2)*ceil(W/2), 4C]."""
+    return _PatchMergeGather.apply(x, H, W, out_dtype or x.dtype)
+
+
+class _InterpRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, idx, wgt):
+        B, S, C = x.shape
+        P = idx.shape[0]
+        ctx.save_for_backward(idx, wgt)
+        ctx.geom = (B, S, P, C)
+        x = x.contiguous()
+        out = torch.empty(B, P, C, dtype=torch.float32, device=x.device)
+        call("pswin_interp_rows", x, ptr(x), ptr(idx), ptr(wgt), ptr(out), B, S, P, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        idx, wgt = ctx.saved_tensors
+        B, S, P, C = ctx.geom
+        dout = dout.contiguous()
+        dx = torch.zeros(B, S, C, dtype=torch.float32, device=dout.device)
+        call("pswin_interp_rows_adjoint", dout, ptr(dout), ptr(idx), ptr(wgt), ptr(dx), B, S, P, C)
+        return dx, None, None
+
+
+def interp_rows(x, idx, wgt):
+    """out[b, p] = sum_k wgt[p, k] x[b, idx[p, k]]: a static bilinear F.grid_sample as a 4-tap row gather."""
+    return _InterpRows.apply(x.float(), idx, wgt)
+
+
+# ------------------------------------------------------------------------------------------------
+# window attention
+# ------------------------------------------------------------------------------------------------
+def build_bias(dist, alpha, beta, mask, n_bias_windows, heads, need_ji):
+    dev = beta.device
+    bias_ij = torch.empty(n_bias_windows, heads, WPAD, WPAD, dtype=torch.float32, device=dev)
+    bias_ji = torch.empty_like(bias_ij) if need_ji else None
+    call("pswin_attn_bias_build", beta, ptr(dist), 0 if dist is None else dist.shape[0], ptr(alpha), ptr(beta),
+         ptr(mask), 0 if mask is None else mask.shape[0], n_bias_windows, heads, ptr(bias_ij), ptr(bias_ji))
+    return bias_ij, bias_ji
+
+
+def _rows_view(t, C):
+    """(tensor, element pointer, row stride) of a [rows, C] view whose last dim is contiguous."""
+    assert t.dim() == 2 and t.shape[1] == C and t.stride(1) == 1, "q/k/v must be [rows, C] with unit inner stride"
+    return t.stride(0)
+
+
+class _WindowAttention(torch.autograd.Function):
+    """softmax(scale q k^T + bias) v per (window, head); q, k, v either slices of one fused [rows, 3C] buffer
+    (k = v = None) or three separate [rows, C] tensors."""
+
+    @staticmethod
+    def forward(ctx, q_or_qkv, k, v, alpha, beta, dist, mask, heads, scale, n_bias_windows):
+        fused = k is None
+        x = q_or_qkv.contiguous()
+        C = heads * _lib.HEAD_DIM
+        rows = x.shape[0]
+        assert rows % WTOK == 0
+        n = rows // WTOK
+        if fused:
+            assert x.shape[1] == 3 * C, "fused qkv must be [rows, 3C] with C = heads * 32"
+            ld = 3 * C
+            es = x.element_size()
+            qp, kp, vp = x.data_ptr(), x.data_ptr() + C * es, x.data_ptr() + 2 * C * es
+        else:
+            k, v = k.contiguous(), v.contiguous()
+            assert x.shape == k.shape == v.shape and x.shape[1] == C
+            assert x.dtype == k.dtype == v.dtype
+            ld = C
+            qp, kp, vp = x.data_ptr(), k.data_ptr(), v.data_ptr()
+        need_grad = any(ctx.needs_input_grad[:5])
+        bias_ij, bias_ji = build_bias(dist, alpha if dist is not None else None, beta, mask, n_bias_windows, heads,
+                                      need_grad)
+        out = torch.empty(rows, C, dtype=x.dtype, device=x.device)
+        lse = torch.empty(n, heads, WPAD, dtype=torch.float32, device=x.device)
+        import ctypes
+        call("pswin_attn_fwd", x, ctypes.c_void_p(qp), ctypes.c_void_p(kp), ctypes.c_void_p(vp), ld, ptr(bias_ij),
+             ptr(out), C, ptr(lse), n, n_bias_windows, heads, float(scale), dtype_code(x))
+        ctx.fused, ctx.heads, ctx.scale, ctx.nb, ctx.n, ctx.C = fused, heads, float(scale), n_bias_windows, n, C
+        ctx.has_dist = dist is not None
+        ctx.save_for_backward(x, k, v, lse, bias_ji, dist)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        import ctypes
+        x, k, v, lse, bias_ji, dist = ctx.saved_tensors
+        heads, n, nb, C = ctx.heads, ctx.n, ctx.nb, ctx.C
+        dout = dout.contiguous()
+        es = x.element_size()
+        if ctx.fused:
+            dx = torch.empty_like(x)
+            ld = 3 * C
+            qp, kp, vp = x.data_ptr(), x.data_ptr() + C * es, x.data_ptr() + 2 * C * es
+            dqp, dkp, dvp = dx.data_ptr(), dx.data_ptr() + C * es, dx.data_ptr() + 2 * C * es
+            dk = dv = None
+        else:
+            dx, dk, dv = torch.empty_like(x), torch.empty_like(k), torch.empty_like(v)
+            ld = C
+            qp, kp, vp = x.data_ptr(), k.data_ptr(), v.data_ptr()
+            dqp, dkp, dvp = dx.data_ptr(), dk.data_ptr(), dv.data_ptr()
+        need_tables = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
+        lib = _lib.load()
+        chunks = lib.pswin_attn_suggest_chunks(n, nb, heads)
+        dbias = (torch.empty(chunks * nb, heads, WPAD, WPAD, dtype=torch.float32, device=x.device)
+                 if need_tables else None)
+        call("pswin_attn_bwd", x, ctypes.c_void_p(qp), ctypes.c_void_p(kp), ctypes.c_void_p(vp), ld, ptr(bias_ji),
+             ptr(dout), C, ptr(lse), ctypes.c_void_p(dqp), ctypes.c_void_p(dkp), ctypes.c_void_p(dvp), ld,
+             ptr(dbias), chunks, n, nb, heads, ctx.scale, dtype_code(x))
+        dalpha = dbeta = None
+        if need_tables:
+            dbeta = torch.empty(169, heads, dtype=torch.float32, device=x.device)
+            dalpha = torch.empty_like(dbeta) if ctx.has_dist else None
+            ws = torch.empty(lib.pswin_attn_bias_bwd_workspace(heads), dtype=torch.float32, device=x.device)
+            call("pswin_attn_bias_bwd", x, ptr(dbias), chunks * nb, nb, ptr(dist), 0 if dist is None else dist.shape[0],
+                 heads, ptr(dalpha), ptr(dbeta), ptr(ws))
+        return dx, dk, dv, dalpha, dbeta, None, None, None, None, None
+
+
+def window_attention(qkv, alpha, beta, dist, mask, heads, scale, n_bias_windows, k=None, v=None):
+    """BasicWindowAttention.forward between qkv and proj (HOT:288-308).
+
+    qkv: [n*49, 3C] (or q with k, v given: three [n*49, C]); alpha/beta: [169, heads] f32 tables;
+    dist: [nW, 49, 49] f32 great-circle table or None (planar: beta only, HOT:257-258);
+    mask: f32 [nM, 49, 49] or None; window n uses bias tile n % n_bias_windows.  Returns [n*49, C].
+    """
+    return _WindowAttention.apply(qkv, k, v, alpha, beta, dist, mask, heads, scale, n_bias_windows)

@@ -1,0 +1,73 @@
+"""The MI355X backbone against the golden fixtures captured from the live reference.  Needs an MI355X."""
+import pytest
+import torch
+
+from _util import TCFG, TINY, TINY_PITCH, build_filled, compare_to_golden, golden, run_and_collect
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _model(cfg, pano, tag, **kw):
+    from panoswintransformerobjectdetection_amd import SimplePanoSwinTransformer
+    return build_filled(lambda **c: SimplePanoSwinTransformer(**c, **kw), cfg, pano, tag).to(DEV)
+
+
+@pytest.mark.parametrize("fixture,cfg,pano,shape,tag", [
+    ("tiny_pano", TINY, True, (2, 3, 64, 128), "tiny"),
+    ("tiny_planar", TINY, False, (2, 3, 64, 128), "tiny"),
+    ("tiny_planar_odd", TINY, False, (2, 3, 60, 100), "tiny"),
+    ("tiny_pano_oddw", TINY, True, (1, 3, 100, 196), "tiny"),
+    ("tiny_pitch_pano", TINY_PITCH, True, (2, 3, 64, 128), "tinyp"),
+    ("tiny_pitch_planar", TINY_PITCH, False, (2, 3, 60, 100), "tinyp"),
+])
+def test_tiny_models_fp32(fixture, cfg, pano, shape, tag):
+    """fp32 tolerance of the north star: outputs rtol 1e-4 / atol 5e-4 on the LayerNorm-ed maps; gradients 1e-3 of
+    their scale (GPU GEMM / conv summation order differs from the CPU reference)."""
+    m = _model(cfg, pano, tag)
+    res = run_and_collect(m, shape, tag, device=DEV)
+    compare_to_golden(res, golden(fixture), rtol=1e-4, atol=5e-4, grad_rtol=2e-3, grad_atol_frac=1e-3)
+
+
+def test_T_512x1024_fp32():
+    m = _model(TCFG, True, "T")
+    res = run_and_collect(m, (2, 3, 512, 1024), "T", device=DEV, subsample_out=4096)
+    compare_to_golden(res, golden("T_512x1024_pano"), rtol=1e-3, atol=2e-3, grad_rtol=1e-2, grad_atol_frac=5e-3)
+
+
+def test_T_512x1024_bf16_close_to_fp32():
+    """bf16 compute (bf16 GEMM/attention operands, fp32 accumulate + residual stream): outputs stay within 5e-2 of
+    the fp32 goldens on the unit-variance LayerNorm-ed maps."""
+    m = _model(TCFG, True, "T", compute_dtype=torch.bfloat16)
+    res = run_and_collect(m, (2, 3, 512, 1024), "T", device=DEV, subsample_out=4096)
+    g = golden("T_512x1024_pano")
+    for i in range(4):
+        ref = torch.from_numpy(g[f"out{i}_sub"])
+        err = (res[f"out{i}_sub"] - ref).abs()
+        assert err.mean().item() < 2e-2 and err.max().item() < 0.25, (i, err.mean().item(), err.max().item())
+
+
+def test_interface_and_state_dict():
+    import panoswintransformerobjectdetection_amd as pkg
+    assert "SimplePanoSwinTransformer" in pkg.BACKBONES.module_dict
+    m = pkg.build_backbone(dict(type="SimplePanoSwinTransformer", **TINY)).to(DEV)
+    m.init_weights(None)
+    assert m.eval() is m
+    with torch.no_grad():
+        outs = m(torch.randn(1, 3, 64, 128, device=DEV), None)
+    assert [tuple(o.shape) for o in outs] == [(1, 32, 16, 32), (1, 64, 8, 16), (1, 128, 4, 8), (1, 256, 2, 4)]
+    assert all(o.dtype == torch.float32 and o.is_contiguous() for o in outs)
+    with pytest.raises(TypeError):
+        m.init_weights(pretrained=1)
+    with pytest.raises(pkg.PswinError):
+        m(torch.randn(1, 3, 64, 128))           # CPU input: no fallback
+
+
+def test_drop_path_and_checkpoint_run():
+    import panoswintransformerobjectdetection_amd as pkg
+    cfg = dict(TINY, drop_path_rate=0.3, use_checkpoint=True)
+    m = pkg.SimplePanoSwinTransformer(**cfg).to(DEV).train()
+    m.init_weights(None)
+    x = torch.randn(2, 3, 64, 128, device=DEV, requires_grad=True)
+    sum(o.mean() for o in m(x)).backward()
+    assert torch.isfinite(x.grad).all()

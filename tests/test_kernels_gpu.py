@@ -1,0 +1,222 @@
+"""HIP kernels (through the C ABI) against the CPU oracle and the golden fixtures.  Needs an MI355X."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import panoswin_oracle as po
+from _util import golden
+from detfill import det_uniform
+
+pytestmark = pytest.mark.gpu
+
+PANO_CASES = [(128, 256), (64, 128), (32, 64), (16, 32), (13, 25), (25, 49), (50, 99), (14, 28)]
+PLANAR_CASES = [(16, 32), (15, 31), (128, 256), (20, 33), (15, 25)]
+
+
+@pytest.fixture(scope="module")
+def ops():
+    import panoswintransformerobjectdetection_amd as pkg
+    pkg.ops.clear_caches()
+    return pkg.ops
+
+
+DEV = "cuda:0"
+
+
+def test_library_loaded_and_abi():
+    from panoswintransformerobjectdetection_amd import _lib
+    lib = _lib.load()
+    assert lib.pswin_version() == _lib.ABI_VERSION
+
+
+def test_index_maps_bit_exact(ops):
+    g = golden("index_maps")
+    for (H, W) in PANO_CASES:
+        for s in (0, 3):
+            wmap, inv, nW = ops.window_maps(True, H, W, s, DEV)
+            assert np.array_equal(wmap.cpu().numpy(), g[f"pano_{H}x{W}_s{s}"]), (H, W, s)
+            assert np.array_equal(inv.cpu().numpy(), g[f"pano_inv_{H}x{W}_s{s}"]), (H, W, s)
+    for (H, W) in PLANAR_CASES:
+        for s in (0, 3):
+            wmap, inv, nW = ops.window_maps(False, H, W, s, DEV)
+            assert np.array_equal(wmap.cpu().numpy(), g[f"planar_{H}x{W}_s{s}"]), (H, W, s)
+            m = wmap.cpu().long()
+            assert torch.equal(m[inv.cpu().long()], torch.arange(H * W))
+        mask = ops.planar_mask(H, W, 3, DEV)
+        assert np.array_equal(mask.cpu().numpy().astype(np.int8), g[f"mask_{H}x{W}"]), (H, W)
+
+
+def test_uv_grid_bit_exact_and_geometry(ops):
+    g = golden("geometry")
+    for (H, W) in [(2, 4), (16, 32), (32, 64), (13, 25), (64, 128)]:
+        assert np.array_equal(ops.uv_grid(H, W, DEV).cpu().numpy().reshape(H, W, 2), g[f"uv_{H}x{W}"]), (H, W)
+    assert np.array_equal(ops.uv_grid(128, 256, DEV).cpu().numpy().reshape(128, 256, 2)[::8, ::8], g["uv_128x256_s8"])
+    feat = ops.abs_pos_features(16, 32, DEV).cpu().numpy().reshape(16, 32, 5)
+    assert np.allclose(feat, g["xyzuv_16x32"], rtol=1e-5, atol=1e-6)
+    for s in (0, 3):
+        wmap, _, nW = ops.window_maps(True, 16, 32, s, DEV)
+        uvw = ops.gather_uv(ops.uv_grid(16, 32, DEV), wmap).view(nW, 49, 2)
+        assert np.array_equal(uvw.cpu().numpy(), g[f"uvwin_16x32_s{s}"])
+        d = ops.window_dist(16, 32, s, DEV).cpu().numpy()
+        assert np.allclose(d, g[f"hav_16x32_s{s}"], rtol=1e-5, atol=2e-6)
+    d = ops.haversine_windows(torch.from_numpy(g["city_uv1"]).to(DEV).repeat(25, 1)[:49][None],
+                              torch.from_numpy(g["city_uv2"]).to(DEV).repeat(25, 1)[:49][None])
+    assert abs(d[0, 0, 0].item() * 6400 - 11187.2852) < 0.05 and abs(d[0, 1, 1].item() * 6400 - 1073.1840) < 0.05
+
+
+@pytest.mark.parametrize("xdt,wdt", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16),
+                                     (torch.bfloat16, torch.bfloat16)])
+@pytest.mark.parametrize("H,W,C,pano,s", [(16, 32, 32, True, 3), (13, 25, 64, True, 0), (15, 31, 96, False, 3),
+                                          (64, 128, 96, True, 3)])
+def test_window_gather_scatter(ops, xdt, wdt, H, W, C, pano, s):
+    B = 2
+    x = det_uniform((B, H * W, C), "gs:x").to(xdt)
+    omap = (po.pano_window_map if pano else po.planar_window_map)(H, W, s)[0]
+    ref_win = po.gather_windows(x.float(), omap)
+    wmap, inv, nW = ops.window_maps(pano, H, W, s, DEV)
+    xd = x.to(DEV).requires_grad_(True)
+    win = ops.window_gather(xd, wmap, inv, wdt)
+    assert win.dtype == wdt and tuple(win.shape) == (B, nW * 49, C)
+    assert torch.equal(win.float().cpu(), ref_win.to(wdt).float())           # pure copy (+ RNE cast): exact
+    # scatter-add with residual and per-sample scale
+    w2 = det_uniform((B, nW * 49, C), "gs:w").to(wdt)
+    scale = torch.tensor([0.0, 1.25])
+    ref = x.float() + scale[:, None, None] * po.scatter_windows(w2.float(), po.invert_window_map(omap, H * W))
+    wd = w2.to(DEV).requires_grad_(True)
+    out = ops.window_scatter_add(wd, xd, wmap, inv, scale.to(DEV))
+    assert torch.allclose(out.float().cpu(), ref.to(xdt).float(), rtol=1e-6 if xdt == torch.float32 else 1e-2, atol=1e-6)
+    # adjoints: gather^T = scatter
+    gout = det_uniform(tuple(out.shape), "gs:g").to(xdt).to(DEV)
+    out.backward(gout)
+    ref_dwin = scale[:, None, None] * po.gather_windows(gout.float().cpu(), omap)
+    assert torch.allclose(wd.grad.float().cpu(), ref_dwin.to(wdt).float(), rtol=1e-2 if wdt == torch.bfloat16 else 1e-6, atol=1e-6)
+    xd.grad = None
+    win.backward(w2.to(DEV))
+    ref_dx = po.scatter_windows(w2.float(), po.invert_window_map(omap, H * W))
+    assert torch.allclose(xd.grad.float().cpu(), ref_dx.to(xdt).float(), rtol=1e-2 if xdt == torch.bfloat16 else 1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("H,W", [(5, 7), (16, 32), (13, 25)])
+def test_patch_merge(ops, H, W):
+    B, C = 2, 32
+    x = det_uniform((B, H * W, C), "pm:x")
+    pm = po.patch_merge_map(H, W)
+    ref = (x[:, pm.clamp(min=0).reshape(-1), :] * (pm.reshape(-1) >= 0).float()[None, :, None]).reshape(B, -1, 4 * C)
+    xd = x.to(DEV).requires_grad_(True)
+    out = ops.patch_merge_gather(xd, H, W)
+    assert torch.equal(out.cpu(), ref)
+    gout = det_uniform(tuple(out.shape), "pm:g")
+    out.backward(gout.to(DEV))
+    xr = x.clone().requires_grad_(True)
+    ((xr[:, pm.clamp(min=0).reshape(-1), :] * (pm.reshape(-1) >= 0).float()[None, :, None]).reshape(B, -1, 4 * C) * gout).sum().backward()
+    assert torch.allclose(xd.grad.cpu(), xr.grad, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("H,W", [(14, 28), (16, 32), (4, 8)])
+def test_pitch_static_resampling(ops, H, W):
+    """interp_rows with the host-built tap tables == the oracle's two F.grid_sample calls."""
+    from panoswintransformerobjectdetection_amd import geometry
+    B, C, ws = 2, 8, 7
+    np_uv = torch.Tensor([1.0, -0.0001]) * math.pi
+    t = geometry.pitch_tables(H, W, ws, np_uv)
+    x = det_uniform((B, H * W, C), "pitch:x").requires_grad_(True)
+    img = F.pad(x.view(B, H, W, C), (0, 0, 0, t["pad_r"], 0, t["pad_b"])).permute(0, 3, 1, 2)
+    ref = po.pitch_rotate_windows(img, ws, np_uv, t["pad_r"], t["pad_b"]).permute(0, 2, 3, 1).reshape(B, -1, C)
+    xd = x.detach().to(DEV).requires_grad_(True)
+    out = ops.interp_rows(ops.interp_rows(xd, t["idx1"].to(DEV), t["w1"].to(DEV)), t["idx2"].to(DEV), t["w2"].to(DEV))
+    assert torch.allclose(out.cpu(), ref, rtol=1e-5, atol=2e-6)
+    gout = det_uniform(tuple(ref.shape), "pitch:g")
+    (ref * gout).sum().backward()
+    out.backward(gout.to(DEV))
+    assert torch.allclose(xd.grad.cpu(), x.grad, rtol=1e-4, atol=1e-5)
+
+
+def _attn_case(n_rep, nW, heads, pano, mask_kind, seed):
+    C = heads * 32
+    n = n_rep * nW
+    x = det_uniform((n * 49, 3 * C), f"att:{seed}:qkv", 1.5)
+    alpha = det_uniform((169, heads), f"att:{seed}:a", 0.3)
+    beta = det_uniform((169, heads), f"att:{seed}:b", 0.3)
+    uv = torch.stack([det_uniform((nW, 49), f"att:{seed}:u", math.pi), det_uniform((nW, 49), f"att:{seed}:v", math.pi / 2)], -1)
+    uv[0, 45:] = 0.0
+    dist = po.haversine(uv, uv) if pano else None
+    mask = None
+    if mask_kind == 3:
+        mask = torch.where(det_uniform((nW, 49, 49), f"att:{seed}:m") > 0.4, torch.tensor(-100.0), torch.tensor(0.0))
+    elif mask_kind == 4:
+        mask = torch.where(det_uniform((n_rep, nW, 49, 49), f"att:{seed}:m4") > 0.4, torch.tensor(-100.0), torch.tensor(0.0))
+    gout = det_uniform((n * 49, C), f"att:{seed}:g", 1.0)
+    return x, alpha, beta, dist, mask, gout
+
+
+def _attn_oracle(x, alpha, beta, dist, mask, gout, heads, n_rep, nW):
+    C = heads * 32
+    x = x.clone().requires_grad_(True)
+    alpha, beta = alpha.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    idx = po.relative_position_index(7).reshape(-1)
+    b = beta[idx].reshape(49, 49, heads)
+    if dist is not None:
+        bias = dist[..., None] * alpha[idx].reshape(49, 49, heads)[None] + b
+        bias = bias.repeat(n_rep, 1, 1, 1)
+    else:
+        bias = b[None]
+    qkv = x.view(-1, 49, 3, C)
+    out = po.window_attention_core(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], 32 ** -0.5, bias.permute(0, 3, 1, 2), mask,
+                                   heads, 0.0, False).reshape(-1, C)
+    (out * gout).sum().backward()
+    return out.detach(), x.grad, alpha.grad, beta.grad
+
+
+@pytest.mark.parametrize("n_rep,nW,heads,pano,mask_kind", [(2, 3, 2, True, 0), (1, 5, 1, False, 0), (2, 3, 3, False, 3),
+                                                           (2, 3, 2, False, 4), (3, 4, 6, True, 3), (8, 15, 24, True, 0)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_window_attention_fwd_bwd(ops, n_rep, nW, heads, pano, mask_kind, dtype):
+    x, alpha, beta, dist, mask, gout = _attn_case(n_rep, nW, heads, pano, mask_kind, f"{n_rep}{nW}{heads}")
+    if dtype == torch.bfloat16:
+        x = x.to(dtype).float()          # the oracle sees the same rounded inputs
+        gout = gout.to(dtype).float()
+    ref_out, ref_dx, ref_da, ref_db = _attn_oracle(x, alpha, beta, dist, mask, gout, heads, n_rep, nW)
+    xd = x.to(DEV).to(dtype).requires_grad_(True)
+    ad, bd = alpha.to(DEV).requires_grad_(True), beta.to(DEV).requires_grad_(True)
+    maskd = None if mask is None else mask.reshape(-1, 49, 49).to(DEV)
+    nb = nW if mask_kind != 4 else n_rep * nW
+    out = ops.window_attention(xd, ad, bd, None if dist is None else dist.to(DEV), maskd, heads, 32 ** -0.5, nb)
+    out.backward(gout.to(DEV).to(dtype))
+    # fp32: exact-f32 MFMA, differs from the oracle by summation order only.  bf16: bf16 operands (q*scale, P and
+    # dS are rounded to bf16), f32 accumulation.
+    rt, at = (2e-5, 2e-5) if dtype == torch.float32 else (3e-2, 3e-2)
+    assert torch.allclose(out.float().cpu(), ref_out, rtol=rt, atol=at)
+    gs = ref_dx.abs().max().item()
+    assert torch.allclose(xd.grad.float().cpu(), ref_dx, rtol=rt * 5, atol=at * gs)
+    assert torch.allclose(bd.grad.cpu(), ref_db, rtol=rt * 5, atol=at * ref_db.abs().max().item())
+    if pano:
+        assert torch.allclose(ad.grad.cpu(), ref_da, rtol=rt * 5, atol=at * ref_da.abs().max().item())
+    else:
+        assert ad.grad is None
+
+
+def test_window_attention_separate_qkv(ops):
+    heads, nW, n_rep = 2, 3, 2
+    C = heads * 32
+    x, alpha, beta, dist, _, gout = _attn_case(n_rep, nW, heads, True, 0, "sep")
+    q, k, v = [x[:, i * C:(i + 1) * C].contiguous() for i in range(3)]
+    fused = ops.window_attention(x.to(DEV), alpha.to(DEV), beta.to(DEV), dist.to(DEV), None, heads, 32 ** -0.5, nW)
+    qd, kd, vd = [t.to(DEV).requires_grad_(True) for t in (q, k, v)]
+    sep = ops.window_attention(qd, alpha.to(DEV), beta.to(DEV), dist.to(DEV), None, heads, 32 ** -0.5, nW, k=kd, v=vd)
+    assert torch.equal(fused, sep)
+    sep.backward(gout.to(DEV))
+    _, ref_dx, _, _ = _attn_oracle(x, alpha, beta, dist, None, gout, heads, n_rep, nW)
+    got = torch.cat([qd.grad, kd.grad, vd.grad], 1).cpu()
+    assert torch.allclose(got, ref_dx, rtol=1e-4, atol=2e-5 * ref_dx.abs().max().item())
+
+
+def test_rejects_cpu_and_bad_args(ops):
+    from panoswintransformerobjectdetection_amd import PswinError
+    with pytest.raises(PswinError):
+        ops.window_gather(torch.zeros(1, 49, 32), torch.zeros(49, dtype=torch.int32), torch.zeros(49, dtype=torch.int32))
+    with pytest.raises(PswinError):          # C not a multiple of 8
+        ops.window_gather(torch.zeros(1, 49, 12, device=DEV), torch.zeros(49, dtype=torch.int32, device=DEV),
+                          torch.zeros(49, dtype=torch.int32, device=DEV))
