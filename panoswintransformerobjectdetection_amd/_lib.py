@@ -101,6 +101,8 @@ def stream_of(t):
 def call(name, ref_tensor, *args):
     """Invoke an entry point on the current stream of ref_tensor's device and raise on a non-zero status."""
     lib = load()
+    if not ref_tensor.is_cuda:
+        raise PswinError(f"{name}: the PanoSwin kernels run on an MI355X (HIP) device only; got a CPU tensor")
     with torch.cuda.device(ref_tensor.device):
         rc = getattr(lib, name)(*args, stream_of(ref_tensor))
     check(rc, name)
