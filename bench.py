@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""Headline benchmark: panoramas/s of PanoSwin-T (512x1024) backbone training steps on N MI355X GPUs.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A step = forward + backward + gradient average (RCCL, N > 1) + AdamW update of the PanoSwin-T backbone on one
+synthetic batch of 8 panoramas per GPU (BASELINE.json configs[1]), bf16 compute with fp32 accumulation /
+master weights.  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+`roofline` is measured live: HIP-event pairs around every launch of the hand-written window-attention kernels
+inside the timed region (on the stream they are launched on); algorithmic bytes per window-head are SURVEY.md
+section 8(d)'s: forward 4 x 49 x 32 x 2 B (Q, K, V in, O out), backward 7 x 49 x 32 x 2 B.
+`cpu_baseline` times the CPU oracle (oracle/panoswin_oracle.py, "port") on this box's host cores, rank 0, N = 1.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+TCFG = dict(embed_dim=96, depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24], window_size=7, ape=True,
+            drop_path_rate=0.2, pano_mode=True)
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md; ~6.3 TB/s achievable)
+TIMED = ("pswin_attn_fwd", "pswin_attn_bwd", "pswin_window_gather", "pswin_window_scatter_add")
+
+
+def cpu_baseline(threads):
+    """CPU oracle, same workload shape at batch 2 (about 10-30 s of CPU work): fwd+bwd panoramas/s."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import panoswin_oracle as po
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    m = po.SimplePanoSwinTransformerOracle(**{**TCFG, "drop_path_rate": 0.0})
+    m.init_weights(None)
+    m.train()
+    x = torch.randn(2, 3, 512, 1024)
+    times = []
+    for it in range(3):
+        t0 = time.perf_counter()
+        m.zero_grad(set_to_none=True)
+        sum(o.float().mean() for o in m(x)).backward()
+        times.append(time.perf_counter() - t0)
+    t = sorted(times[1:])[0]
+    return {"value": round(2 / t, 4), "unit": "panoramas/s", "cores": threads, "kind": "port",
+            "sample": "PanoSwin-T fwd+bwd, batch 2 x 3x512x1024 fp32, best of 2 after 1 warm-up, CPU oracle"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="panoramas per GPU")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--bucket-mb", type=float, default=32.0)
+    args = ap.parse_args()
+
+    from panoswintransformerobjectdetection_amd import SimplePanoSwinTransformer, _lib
+    from panoswintransformerobjectdetection_amd.dp import GradReducer, init_distributed
+
+    rank, local_rank, world = init_distributed()
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    _lib.load()                                  # fail loudly if the HIP library is missing
+
+    torch.manual_seed(0)
+    cd = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    model = SimplePanoSwinTransformer(**TCFG, compute_dtype=cd)
+    model.init_weights(None)
+    model = model.to(dev).train()
+    reducer = GradReducer(model, bucket_mb=args.bucket_mb)
+    reducer.broadcast_parameters(model)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, betas=(0.9, 0.999), weight_decay=0.05, fused=True)
+
+    torch.manual_seed(1234 + rank)               # every rank its own shard of synthetic panoramas
+    x = torch.randn(args.batch, 3, 512, 1024, device=dev)
+
+    def step():
+        reducer.zero_grad()
+        outs = model(x)
+        loss = sum(o.float().mean() for o in outs)
+        loss.backward()
+        reducer.finish()
+        opt.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    _lib.enable_timing(TIMED)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kern = _lib.disable_timing()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(loss).item(), "non-finite loss"
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = args.batch * world * args.steps / elapsed
+        stats = {}
+        for name, recs in kern.items():
+            if recs:
+                tot_ms = sum(r[0] for r in recs)
+                tot_b = sum(r[1] for r in recs)
+                stats[name] = {"launches": len(recs), "avg_us": round(tot_ms / len(recs) * 1e3, 2),
+                               "ms_per_step": round(tot_ms / args.steps, 3),
+                               "GBps": round(tot_b / (tot_ms * 1e-3) / 1e9, 1)}
+        dom = max(("pswin_attn_fwd", "pswin_attn_bwd"), key=lambda n: stats.get(n, {}).get("ms_per_step", 0.0))
+        recs = kern[dom]
+        achieved = sum(r[1] for r in recs) / (sum(r[0] for r in recs) * 1e-3) / 1e9
+        roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "avg_launch_us": stats[dom]["avg_us"], "kernels": stats}
+        line = {
+            "metric": "panoramas/sec PanoSwin-T 512x1024 fwd+bwd", "value": round(value, 2), "unit": "panoramas/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "PanoSwin-T backbone (embed 96, depths 2-2-6-2, heads 3-6-12-24, ape, pano mode) "
+                                   "fwd+bwd+AdamW on 3x512x1024 panoramas, BASELINE.json configs[1]",
+                       "batch_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
+                       "grad_bucket_mb": args.bucket_mb, "device": torch.cuda.get_device_name(dev)},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                cores = len(os.sched_getaffinity(0))
+            except AttributeError:
+                cores = os.cpu_count() or 1
+            line["cpu_baseline"] = cpu_baseline(min(cores, 16))      # the box's CPU share for one GPU is 16
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -98,13 +98,41 @@ def stream_of(t):
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
-def call(name, ref_tensor, *args):
+# Optional per-launch timing (bench.py): name -> list of (start_event, end_event, algorithmic_bytes).  The events
+# are recorded on the stream the kernel is launched on (torch's current stream), around that launch only.
+_TIMED = None
+
+
+def enable_timing(names):
+    """Start collecting HIP-event pairs around every launch of the named entry points."""
+    global _TIMED
+    _TIMED = {n: [] for n in names}
+
+
+def disable_timing():
+    """Stop collecting; returns {name: [(milliseconds, algorithmic_bytes), ...]} (synchronises)."""
+    global _TIMED
+    rec, _TIMED = _TIMED, None
+    if rec is None:
+        return {}
+    torch.cuda.synchronize()
+    return {n: [(s.elapsed_time(e), b) for s, e, b in lst] for n, lst in rec.items()}
+
+
+def call(name, ref_tensor, *args, algo_bytes=0):
     """Invoke an entry point on the current stream of ref_tensor's device and raise on a non-zero status."""
     lib = load()
     if not ref_tensor.is_cuda:
         raise PswinError(f"{name}: the PanoSwin kernels run on an MI355X (HIP) device only; got a CPU tensor")
     with torch.cuda.device(ref_tensor.device):
-        rc = getattr(lib, name)(*args, stream_of(ref_tensor))
+        if _TIMED is not None and name in _TIMED:
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            rc = getattr(lib, name)(*args, stream_of(ref_tensor))
+            e.record()
+            _TIMED[name].append((s, e, algo_bytes))
+        else:
+            rc = getattr(lib, name)(*args, stream_of(ref_tensor))
     check(rc, name)
 
 

@@ -1,0 +1,113 @@
+"""Data-parallel gradient averaging over RCCL (xGMI), one process per GPU.
+
+Replaces the reference's DP wiring -- tools/dist_train.sh:8-9 (one process per device), tools/train.py:126-134
+(init_dist, backend nccl) and mmdet/apis/train.py:91-99 (MMDistributedDataParallel: bucketed NCCL all-reduce of
+every gradient, broadcast_buffers=False so BatchNorm statistics stay per rank, find_unused_parameters).
+Contract reproduced: after ``finish()`` every rank holds mean_over_ranks(local grad) for every parameter; buffers
+are never synchronised; parameters that received no gradient contribute zeros.
+
+MI355X-first choices
+  * all gradients live in ONE flat fp32 buffer (``param.grad`` are views into it): zeroing is one memset, the
+    optimizer can run over contiguous memory, and a bucket is just a slice -- no flatten / unflatten copies;
+  * buckets are cut in reverse registration order (the order backward produces gradients) and each is launched
+    as soon as its last gradient has been accumulated, from a post-accumulate hook, so RCCL runs on its own
+    stream under the remaining backward kernels;
+  * xGMI is a point-to-point mesh (7 links per GPU): few large messages beat many small ones, hence the default
+    32 MiB buckets (4 launches for the 110 MB of PanoSwin-T gradients) and ``ReduceOp.AVG`` in the collective
+    itself instead of a separate divide pass.
+"""
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend=None):
+    """Rendezvous from the torchrun environment (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT)."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"     # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+class GradReducer:
+    def __init__(self, module, bucket_mb=32.0, process_group=None):
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.params = [p for p in module.parameters() if p.requires_grad]
+        if not self.params:
+            raise ValueError("no trainable parameters")
+        dev = self.params[0].device
+        order = list(reversed(self.params))                       # ~ the order in which backward finishes them
+        offsets, total = [], 0
+        for p in order:
+            offsets.append(total)
+            total += (p.numel() + 63) // 64 * 64                  # keep every view 256-byte aligned
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.buckets = []                                         # [start, end, n_params]
+        self._bucket_of = {}
+        limit = int(bucket_mb * 1024 * 1024 / 4)
+        start = 0
+        count = 0
+        for i, p in enumerate(order):
+            p.grad = self.flat[offsets[i]:offsets[i] + p.numel()].view_as(p)
+            self._bucket_of[p] = len(self.buckets)
+            count += 1
+            end = offsets[i + 1] if i + 1 < len(order) else total
+            if end - start >= limit or i + 1 == len(order):
+                self.buckets.append([start, end, count])
+                start, count = end, 0
+        self._pending = [b[2] for b in self.buckets]
+        self._launched = [False] * len(self.buckets)
+        self._handles = []
+        self._use_avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params] if self.world > 1 else []
+
+    # -- per step -----------------------------------------------------------------------------------------------
+    def zero_grad(self):
+        self.flat.zero_()
+
+    def _launch(self, b):
+        if self._launched[b]:
+            return
+        self._launched[b] = True
+        s, e, _ = self.buckets[b]
+        view = self.flat[s:e]
+        if self._use_avg:
+            self._handles.append((dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group, async_op=True), None))
+        else:                                                     # gloo (CPU tests): SUM then divide
+            self._handles.append((dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True), view))
+
+    def _on_grad(self, p):
+        b = self._bucket_of[p]
+        self._pending[b] -= 1
+        if self._pending[b] == 0:
+            self._launch(b)
+
+    def finish(self):
+        """Call after backward: launches buckets whose parameters got no gradient, waits for all of them."""
+        if self.world > 1:
+            for b in range(len(self.buckets)):
+                self._launch(b)
+            for h, view in self._handles:
+                h.wait()
+                if view is not None:
+                    view.div_(self.world)
+        self._handles = []
+        self._pending = [b[2] for b in self.buckets]
+        self._launched = [False] * len(self.buckets)
+
+    # -- once ---------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def broadcast_parameters(self, module, src=0):
+        """Make every rank start from rank `src`'s weights (DDP does this at construction); buffers are left alone
+        (broadcast_buffers=False in the reference)."""
+        if self.world == 1:
+            return
+        for p in module.parameters():
+            dist.broadcast(p.data, src=src, group=self.group)

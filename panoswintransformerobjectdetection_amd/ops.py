@@ -103,8 +103,9 @@ def window_dist(H, W, shift, device):
 def _gather_raw(x, wmap, scale, n_slots, out_dtype):
     B, S, C = x.shape
     win = torch.empty(B, n_slots, C, dtype=out_dtype, device=x.device)
+    nreal = min(S, n_slots)
     call("pswin_window_gather", x, ptr(x), dtype_code(x), ptr(wmap), ptr(scale), ptr(win), dtype_code(win), B, S,
-         n_slots, C)
+         n_slots, C, algo_bytes=B * C * (nreal * x.element_size() + n_slots * win.element_size()))
     return win
 
 
@@ -112,7 +113,8 @@ def _scatter_raw(win, inv, resid, scale, S, out_dtype):
     B, n_slots, C = win.shape
     out = torch.empty(B, S, C, dtype=out_dtype, device=win.device)
     call("pswin_window_scatter_add", win, ptr(win), dtype_code(win), ptr(inv), ptr(resid), ptr(scale), ptr(out),
-         dtype_code(out), B, S, n_slots, C)
+         dtype_code(out), B, S, n_slots, C,
+         algo_bytes=B * S * C * (win.element_size() + out.element_size() * (1 if resid is None else 2)))
     return out
 
 
@@ -255,7 +257,8 @@ class _WindowAttention(torch.autograd.Function):
         lse = torch.empty(n, heads, WPAD, dtype=torch.float32, device=x.device)
         import ctypes
         call("pswin_attn_fwd", x, ctypes.c_void_p(qp), ctypes.c_void_p(kp), ctypes.c_void_p(vp), ld, ptr(bias_ij),
-             ptr(out), C, ptr(lse), n, n_bias_windows, heads, float(scale), dtype_code(x))
+             ptr(out), C, ptr(lse), n, n_bias_windows, heads, float(scale), dtype_code(x),
+             algo_bytes=n * heads * 4 * WTOK * _lib.HEAD_DIM * x.element_size())
         ctx.fused, ctx.heads, ctx.scale, ctx.nb, ctx.n, ctx.C = fused, heads, float(scale), n_bias_windows, n, C
         ctx.has_dist = dist is not None
         ctx.save_for_backward(x, k, v, lse, bias_ji, dist)
@@ -286,7 +289,8 @@ class _WindowAttention(torch.autograd.Function):
                  if need_tables else None)
         call("pswin_attn_bwd", x, ctypes.c_void_p(qp), ctypes.c_void_p(kp), ctypes.c_void_p(vp), ld, ptr(bias_ji),
              ptr(dout), C, ptr(lse), ctypes.c_void_p(dqp), ctypes.c_void_p(dkp), ctypes.c_void_p(dvp), ld,
-             ptr(dbias), chunks, n, nb, heads, ctx.scale, dtype_code(x))
+             ptr(dbias), chunks, n, nb, heads, ctx.scale, dtype_code(x),
+             algo_bytes=n * heads * 7 * WTOK * _lib.HEAD_DIM * x.element_size())
         dalpha = dbeta = None
         if need_tables:
             dbeta = torch.empty(169, heads, dtype=torch.float32, device=x.device)
