@@ -20,6 +20,13 @@ import os
 import sys
 import time
 
+# A fresh box has no MIOpen user find-db, so the first bf16 NHWC PatchEmbed convolutions would trigger a ~45 s
+# solver search in every process (MIOPEN_FIND_MODE=FAST avoids the search but falls back to naive kernels, 30x
+# slower).  The results of that search for the bench shapes are shipped with the package and used when present.
+_MIOPEN_DB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "panoswintransformerobjectdetection_amd", "miopen_db")
+if os.path.isdir(_MIOPEN_DB):
+    os.environ.setdefault("MIOPEN_USER_DB_PATH", _MIOPEN_DB)
+
 import torch
 import torch.distributed as dist
 
@@ -62,6 +69,9 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bucket-mb", type=float, default=32.0)
+    ap.add_argument("--eager", action="store_true", help="do not capture the step into a HIP graph")
+    ap.add_argument("--kernel-steps", type=int, default=3,
+                    help="eager steps run after the timed region to time individual kernels with HIP events")
     args = ap.parse_args()
 
     from panoswintransformerobjectdetection_amd import SimplePanoSwinTransformer, _lib
@@ -81,19 +91,40 @@ def main():
     model = model.to(dev).train()
     reducer = GradReducer(model, bucket_mb=args.bucket_mb)
     reducer.broadcast_parameters(model)
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, betas=(0.9, 0.999), weight_decay=0.05, fused=True)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, betas=(0.9, 0.999), weight_decay=0.05, fused=True,
+                            capturable=not args.eager)
 
     torch.manual_seed(1234 + rank)               # every rank its own shard of synthetic panoramas
     x = torch.randn(args.batch, 3, 512, 1024, device=dev)
 
-    def step():
+    def fwd_bwd():
         reducer.zero_grad()
         outs = model(x)
         loss = sum(o.float().mean() for o in outs)
         loss.backward()
+        return loss
+
+    def eager_step():
+        loss = fwd_bwd()
         reducer.finish()
         opt.step()
         return loss
+
+    if args.eager:
+        step = eager_step
+    else:
+        # One hipGraph for forward+backward, one for the optimizer; the RCCL all-reduce of the flat gradient buffer
+        # runs between the two replays (N > 1), so collectives are never part of a captured graph.
+        from panoswintransformerobjectdetection_amd.graph import GraphedCallable
+        reducer.overlap = False                  # hooks must not launch collectives during capture
+        g_fb = GraphedCallable(fwd_bwd, warmup=2)
+        g_opt = GraphedCallable(opt.step, warmup=1)
+
+        def step():
+            loss = g_fb()
+            reducer.finish()
+            g_opt()
+            return loss
 
     def barrier():
         if world > 1:
@@ -103,13 +134,21 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    _lib.enable_timing(TIMED)
+    if args.eager:
+        _lib.enable_timing(TIMED)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
     barrier()
     elapsed = time.perf_counter() - t0
+    if not args.eager:
+        # Nodes of a replayed graph cannot be bracketed by host-recorded events, so the per-kernel HIP-event timing
+        # runs on eager steps of the same model / batch right after the timed region (same kernels, shapes, data).
+        _lib.enable_timing(TIMED)
+        for _ in range(args.kernel_steps):
+            eager_step()
     kern = _lib.disable_timing()
+    ksteps = args.steps if args.eager else args.kernel_steps
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -125,7 +164,7 @@ def main():
                 tot_ms = sum(r[0] for r in recs)
                 tot_b = sum(r[1] for r in recs)
                 stats[name] = {"launches": len(recs), "avg_us": round(tot_ms / len(recs) * 1e3, 2),
-                               "ms_per_step": round(tot_ms / args.steps, 3),
+                               "ms_per_step": round(tot_ms / ksteps, 3),
                                "GBps": round(tot_b / (tot_ms * 1e-3) / 1e9, 1)}
         dom = max(("pswin_attn_fwd", "pswin_attn_bwd"), key=lambda n: stats.get(n, {}).get("ms_per_step", 0.0))
         recs = kern[dom]
@@ -140,7 +179,8 @@ def main():
             "config": {"workload": "PanoSwin-T backbone (embed 96, depths 2-2-6-2, heads 3-6-12-24, ape, pano mode) "
                                    "fwd+bwd+AdamW on 3x512x1024 panoramas, BASELINE.json configs[1]",
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                       "grad_bucket_mb": args.bucket_mb, "device": torch.cuda.get_device_name(dev)},
+                       "grad_bucket_mb": args.bucket_mb, "hip_graph": not args.eager,
+                       "device": torch.cuda.get_device_name(dev)},
             "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:

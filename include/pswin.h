@@ -113,6 +113,37 @@ int pswin_window_scatter_add(const void* win, int win_dtype, const int32_t* inv,
                              const float* scale, void* out, int x_dtype, int B, int S, int n_slots, int C,
                              void* stream);
 
+/* LayerNorm fused into the window gather: y[b][slot][:] = LN(x[b][map[slot]][:]) * gamma + beta, zero rows in the
+ * padding slots (the reference pads AFTER norm1: HOT:504, 512).  Replaces norm1 + WindowTransition + pad_x +
+ * window_partition (HOT:503-513).  With map == NULL (then n_out must equal S) it is a plain row LayerNorm: norm2
+ * (HOT:534), PatchEmbed.norm (HOT:771), the output norms (HOT:975-976).
+ * Statistics (biased variance, eps inside the sqrt, as nn.LayerNorm) are fp32 and stored per SOURCE token:
+ * mean, rstd: f32 [B, S].  x: [B, S, C] x_dtype; y: [B, n_out, C] y_dtype; gamma, beta: f32 [C]; 8 <= C <= 2048, C % 8 == 0. */
+int pswin_ln_gather_fwd(const void* x, int x_dtype, const int32_t* map, const float* gamma, const float* beta, float eps,
+                        void* y, int y_dtype, float* mean, float* rstd, int B, int S, int n_out, int C, void* stream);
+
+/* Its backward: for every token (b, t), dy row = dy[b][inv ? inv[t] : t] and
+ *   dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma, xhat = (x - mean) * rstd;
+ *   dgamma = sum dy * xhat, dbeta = sum dy (block partials in `workspace`, reduced in a fixed order).
+ * dy: [B, n_out, C] dy_dtype; dx: [B, S, C] x_dtype; workspace: f32, pswin_ln_workspace(B * S, C) elements. */
+int pswin_ln_gather_bwd(const void* dy, int dy_dtype, const int32_t* inv, const void* x, int x_dtype, const float* mean,
+                        const float* rstd, const float* gamma, void* dx, float* dgamma, float* dbeta, float* workspace,
+                        int B, int S, int n_out, int C, void* stream);
+
+/* Workspace elements for the LayerNorm backward kernels over `rows` walked rows of width C. */
+int pswin_ln_workspace(long long rows, int C);
+
+/* PatchMerging gather fused with its LayerNorm(4C) (HOT:563-574): y[b][i*W2+j] = LN(concat of the 4 tokens).
+ * x: [B, H*W, C]; y: [B, H2*W2, 4C]; gamma, beta: f32 [4C]; mean, rstd: f32 [B, H2*W2]; C % 16 == 0, 4C <= 2048. */
+int pswin_ln_patch_merge_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, float eps, void* y,
+                             int y_dtype, float* mean, float* rstd, int B, int H, int W, int C, void* stream);
+
+/* Its backward; dx: [B, H*W, C] (every token belongs to exactly one merged row);
+ * workspace: pswin_ln_workspace(B * H2 * W2, 4 * C) elements. */
+int pswin_ln_patch_merge_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean,
+                             const float* rstd, const float* gamma, void* dx, float* dgamma, float* dbeta,
+                             float* workspace, int B, int H, int W, int C, void* stream);
+
 /* PatchMerging gather (HOT:560-573): out[b][i*W2+j][k*C + c] = x[b][(2i+dy_k)*W + 2j+dx_k][c] or 0 outside,
  * (dy,dx)_k = (0,0),(1,0),(0,1),(1,1); H2 = ceil(H/2), W2 = ceil(W/2).  x: [B, H*W, C], out: [B, H2*W2, 4C]. */
 int pswin_patch_merge_gather(const void* x, int x_dtype, void* out, int out_dtype, int B, int H, int W, int C,

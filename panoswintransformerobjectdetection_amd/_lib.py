@@ -28,6 +28,11 @@ _PROTOTYPES = {
     "pswin_haversine_windows": [_vp, _vp, _i, _vp, _vp],
     "pswin_window_gather": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "pswin_window_scatter_add": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "pswin_ln_gather_fwd": [_vp, _i, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
+    "pswin_ln_gather_bwd": [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "pswin_ln_workspace": [ctypes.c_longlong, _i],
+    "pswin_ln_patch_merge_fwd": [_vp, _i, _vp, _vp, _f, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
+    "pswin_ln_patch_merge_bwd": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "pswin_patch_merge_gather": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "pswin_patch_merge_scatter": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "pswin_interp_rows": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],

@@ -74,8 +74,7 @@ class Mlp(nn.Module):
         self.fc2 = nn.Linear(hidden_features, in_features)
 
     def forward(self, x, cd):
-        x = F.gelu(F.linear(x.to(cd), self.fc1.weight.to(cd), self.fc1.bias.to(cd)))
-        return F.linear(x, self.fc2.weight.to(cd), self.fc2.bias.to(cd))
+        return _linear(F.gelu(_linear(x, self.fc1, cd)), self.fc2, cd)
 
 
 class WindowAttention(nn.Module, DoubleModeModule):
@@ -95,8 +94,56 @@ class WindowAttention(nn.Module, DoubleModeModule):
             self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
 
 
+def _pick_split(M, n_tiles):
+    """Number of K-splits for a weight-gradient GEMM with contraction length M and n_tiles output tiles: a divisor
+    of M that gives hipBLASLt about a thousand independent tiles while each split keeps >= 512 rows."""
+    want = max(1, min(M // 512, -(-1024 // n_tiles)))
+    best = 1
+    for c in range(1, min(M, 4 * want) + 1):
+        if M % c == 0 and abs(c - want) < abs(best - want):
+            best = c
+    return best
+
+
+class _LinearSplitK(torch.autograd.Function):
+    """y = x W^T + b with bf16 operands and fp32 master parameters.
+
+    Forward and dX are plain hipBLASLt GEMMs.  dW = dY^T X contracts over up to 275k window tokens into an output of
+    a few dozen tiles, which a single GEMM launch maps onto a few dozen workgroups (measured 470-535 us for the
+    stage-0 shapes on MI355X against a 20-50 us HBM floor); it is issued as a batched GEMM over row chunks (an
+    explicit split-K, 55-75 us) whose fp32 partial sum also removes the bf16 -> fp32 gradient cast."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        wb = weight.to(x.dtype)
+        ctx.save_for_backward(x, wb)
+        ctx.has_bias = bias is not None
+        return F.linear(x, wb, None if bias is None else bias.to(x.dtype))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wb = ctx.saved_tensors
+        dy = dy.contiguous()
+        M, N = dy.shape
+        K = x.shape[1]
+        dx = dy @ wb if ctx.needs_input_grad[0] else None
+        ch = _pick_split(M, -(-N // 64) * -(-K // 64))
+        if ch > 1:
+            part = torch.bmm(dy.view(ch, M // ch, N).transpose(1, 2), x.view(ch, M // ch, K))
+            dw = part.sum(0, dtype=torch.float32)
+        else:
+            dw = (dy.t() @ x).float()
+        db = dy.sum(0, dtype=torch.float32) if ctx.has_bias else None
+        return dx, dw, db
+
+
 def _linear(x, lin, cd):
-    return F.linear(x.to(cd), lin.weight.to(cd), None if lin.bias is None else lin.bias.to(cd))
+    """nn.Linear on rows.  fp32: F.linear (parity path).  bf16: split-K weight gradient, fp32 parameter gradients."""
+    if cd == torch.float32:
+        return F.linear(x.float(), lin.weight, lin.bias)
+    shp = x.shape
+    x2 = x.to(cd).reshape(-1, shp[-1])
+    return _LinearSplitK.apply(x2, lin.weight, lin.bias).view(*shp[:-1], lin.weight.shape[0])
 
 
 class PanoSwinTransformerBlock(nn.Module, DoubleModeModule):
@@ -125,15 +172,16 @@ class PanoSwinTransformerBlock(nn.Module, DoubleModeModule):
             dist = None
             mask = ops.planar_mask(H, W, self.shift_size, dev) if self.shift_size else None   # HOT:474
         a = self.attn
-        xn = F.layer_norm(x, (C,), self.norm1.weight, self.norm1.bias, self.norm1.eps)
-        win = ops.window_gather(xn, wmap, inv, cd)                                # [B, nW*49, C]
+        n1 = self.norm1                                                           # norm1 + shift + pad + partition
+        win = ops.layer_norm_gather(x, n1.weight, n1.bias, n1.eps, wmap, inv, cd)  # [B, nW*49, C]
         qkv = _linear(win.view(-1, C), a.qkv, cd)                                 # [B*nW*49, 3C]
         att = ops.window_attention(qkv, a.sphere_position_alpha_table_Te, a.sphere_position_beta_table_Te, dist, mask,
                                    a.num_heads, a.scale, nW)
         att = _linear(att, a.proj, cd).view(B, nW * WTOK, C)
         scale = _drop_path_scale(x, self.drop_path_p, self.training)
         x = ops.window_scatter_add(att, x, wmap, inv, scale)                      # shortcut + DropPath(attn)
-        y = self.mlp(F.layer_norm(x, (C,), self.norm2.weight, self.norm2.bias, self.norm2.eps), cd)
+        n2 = self.norm2
+        y = self.mlp(ops.layer_norm_gather(x, n2.weight, n2.bias, n2.eps, out_dtype=cd), cd)
         if scale is not None:
             y = y * scale.to(y.dtype)[:, None, None]
         return x + y.to(x.dtype)
@@ -177,7 +225,7 @@ class PitchAttentionModule(WindowAttention):
         dev = x.device
         pano = bool(self.pano_mode)
         wmap, inv, nW = ops.window_maps(False, H, W, 0, dev)
-        xn = F.layer_norm(x, (C,), self.norm1.weight, self.norm1.bias, self.norm1.eps)
+        xn = ops.layer_norm_gather(x, self.norm1.weight, self.norm1.bias, self.norm1.eps)
         win = ops.window_gather(xn, wmap, inv, cd).view(-1, C)
         if pano:
             t = self._tables(H, W, dev)
@@ -191,7 +239,7 @@ class PitchAttentionModule(WindowAttention):
         att = _linear(att, self.proj, cd).view(B, nW * WTOK, C)
         # the reference overwrites its own shortcut with LN(x) (in-place norm on a view, HOT:1154-1155): residual = xn
         x = ops.window_scatter_add(att, xn, wmap, inv, None)
-        y = self.mlp(F.layer_norm(x, (C,), self.norm2.weight, self.norm2.bias, self.norm2.eps), cd)
+        y = self.mlp(ops.layer_norm_gather(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, out_dtype=cd), cd)
         return x + y.to(x.dtype)
 
 
@@ -207,8 +255,7 @@ class PatchMerging(nn.Module):
     def forward(self, x, H, W, cd):
         B, S, C = x.shape
         assert S == H * W, "input feature has wrong size"
-        g = ops.patch_merge_gather(x, H, W)
-        g = F.layer_norm(g, (4 * C,), self.norm.weight, self.norm.bias, self.norm.eps)
+        g = ops.layer_norm_patch_merge(x, self.norm.weight, self.norm.bias, self.norm.eps, H, W, cd)
         return _linear(g, self.reduction, cd).to(x.dtype)
 
 
@@ -260,19 +307,20 @@ class PatchEmbed(nn.Module):
             nn.Conv2d(c * 2, embed_dim, kernel_size=self.patch_size, stride=self.patch_size))
         self.norm = nn.LayerNorm(embed_dim) if norm else None
 
-    def forward(self, x):
+    def forward(self, x, cd=torch.float32):
         _, _, H, W = x.shape
         ph, pw = self.patch_size
         if W % pw:
             x = F.pad(x, (0, pw - W % pw))
         if H % ph:
             x = F.pad(x, (0, 0, 0, ph - H % ph))
-        x = self.proj(x.contiguous(memory_format=torch.channels_last))
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=(cd == torch.bfloat16)):
+            x = self.proj(x.contiguous(memory_format=torch.channels_last))      # bf16: MIOpen NHWC bf16 convolutions
         B, C, Wh, Ww = x.shape
-        tok = x.permute(0, 2, 3, 1).reshape(B, Wh * Ww, C)         # free for a channels-last tensor
-        if self.norm is not None:
-            tok = F.layer_norm(tok, (C,), self.norm.weight, self.norm.bias, self.norm.eps)
-        return tok, Wh, Ww
+        tok = x.permute(0, 2, 3, 1).reshape(B, Wh * Ww, C)          # free for a channels-last tensor
+        if self.norm is not None:                                    # reads bf16 or fp32, writes the fp32 residual stream
+            tok = ops.layer_norm_gather(tok, self.norm.weight, self.norm.bias, self.norm.eps, out_dtype=torch.float32)
+        return tok.float(), Wh, Ww
 
 
 @BACKBONES.register_module()
@@ -353,7 +401,7 @@ class SimplePanoSwinTransformer(nn.Module, DoubleModeModule):
         if not x_bchw.is_cuda:
             raise PswinError("SimplePanoSwinTransformer (MI355X build) needs its input on a HIP device")
         cd = self.compute_dtype
-        x, Wh, Ww = self.patch_embed(x_bchw.float())
+        x, Wh, Ww = self.patch_embed(x_bchw.float(), cd)
         if self.pano_mode and self.ape:
             feat = ops.abs_pos_features(Wh, Ww, x.device)                               # HOT:926-934
             x = x + F.linear(feat, self.abs_encoder.weight, self.abs_encoder.bias)[None]
@@ -362,7 +410,7 @@ class SimplePanoSwinTransformer(nn.Module, DoubleModeModule):
             x_out, H, W, x, Wh, Ww = layer(x, Wh, Ww, cd)
             if i in self.out_indices:
                 nl = getattr(self, f"norm{i}")
-                y = F.layer_norm(x_out, (self.num_features[i],), nl.weight, nl.bias, nl.eps)
+                y = ops.layer_norm_gather(x_out, nl.weight, nl.bias, nl.eps)
                 outs.append(y.view(-1, H, W, self.num_features[i]).permute(0, 3, 1, 2).contiguous())
         return tuple(outs)
 

@@ -512,42 +512,65 @@ __global__ void bias_build_kernel(const float* __restrict__ dist, int n_dist, co
 }
 
 constexpr int NBINS = (2 * PSWIN_WS - 1) * (2 * PSWIN_WS - 1);   // 169
-constexpr int BIAS_BWD_BLOCKS = 64;
+constexpr int BIAS_BWD_BLOCKS = 128;
+constexpr int BIAS_BWD_THREADS = 256;
+constexpr int BIAS_BWD_EPT = (TOK * TOK + BIAS_BWD_THREADS - 1) / BIAS_BWD_THREADS;   // 10 (i, j) pairs per thread
 
-// partial[block][h][2][169]: block-local bin sums over a strided subset of the tiles
-__global__ void bias_bwd_partial_kernel(const float* __restrict__ dbias_ji, int n_tiles, int nb,
-                                        const float* __restrict__ dist, int n_dist, int heads,
-                                        float* __restrict__ partial) {
-    __shared__ float bins[2][NBINS];
+// Stage 1: per block and head, sum over a strided subset of the tiles of g and g * dist for every (i, j) pair.
+// No atomics: a thread owns the same 10 pairs for every tile, so the sums stay in registers.
+// partial[block][h][2][49*49]
+__global__ __launch_bounds__(BIAS_BWD_THREADS) void bias_bwd_partial_kernel(
+    const float* __restrict__ dbias_ji, int n_tiles, int nb, const float* __restrict__ dist, int n_dist, int heads,
+    float* __restrict__ partial) {
     const int h = blockIdx.y;
-    for (int t = threadIdx.x; t < 2 * NBINS; t += blockDim.x) (&bins[0][0])[t] = 0.f;
-    __syncthreads();
+    float sb[BIAS_BWD_EPT], sa[BIAS_BWD_EPT];
+#pragma unroll
+    for (int k = 0; k < BIAS_BWD_EPT; ++k) sb[k] = sa[k] = 0.f;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const float* gt = dbias_ji + ((size_t)tile * heads + h) * (PADT * PADT);
-        const int wb = tile % nb;
-        for (int e = threadIdx.x; e < TOK * TOK; e += blockDim.x) {
-            const int j = e / TOK, i = e - j * TOK;     // consecutive threads walk i (contiguous in the ji tile)
-            const float gval = gt[j * PADT + i];
-            const int idx = rel_index(i, j);
-            atomicAdd(&bins[0][idx], gval);
-            if (dist) atomicAdd(&bins[1][idx], gval * dist[((size_t)(wb % n_dist) * TOK + i) * TOK + j]);
+        const float* dt = dist ? dist + (size_t)((tile % nb) % n_dist) * TOK * TOK : nullptr;
+#pragma unroll
+        for (int k = 0; k < BIAS_BWD_EPT; ++k) {
+            const int e = threadIdx.x + k * BIAS_BWD_THREADS;      // e = j * 49 + i: i contiguous in the ji tile
+            if (e < TOK * TOK) {
+                const int j = e / TOK, i = e - j * TOK;
+                const float gval = gt[j * PADT + i];
+                sb[k] += gval;
+                if (dt) sa[k] += gval * dt[i * TOK + j];
+            }
         }
     }
-    __syncthreads();
-    float* out = partial + ((size_t)blockIdx.x * heads + h) * 2 * NBINS;
-    for (int t = threadIdx.x; t < 2 * NBINS; t += blockDim.x) out[t] = (&bins[0][0])[t];
+    float* out = partial + ((size_t)blockIdx.x * heads + h) * 2 * TOK * TOK;
+#pragma unroll
+    for (int k = 0; k < BIAS_BWD_EPT; ++k) {
+        const int e = threadIdx.x + k * BIAS_BWD_THREADS;
+        if (e < TOK * TOK) {
+            out[e] = sb[k];
+            out[TOK * TOK + e] = sa[k];
+        }
+    }
 }
 
-__global__ void bias_bwd_final_kernel(const float* __restrict__ partial, int n_blocks, int heads,
+// Stage 2 (after the column sum over blocks): one thread per (table entry, head) adds the <= 49 pairs of its entry.
+// summed: [heads][2][49*49]
+__global__ void bias_bwd_final_kernel(const float* __restrict__ summed, int heads, bool has_dist,
                                       float* __restrict__ dalpha, float* __restrict__ dbeta) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;   // over 169 * heads
     if (t >= NBINS * heads) return;
     const int idx = t / heads, h = t - idx * heads;
+    const int dh = idx / (2 * PSWIN_WS - 1) - (PSWIN_WS - 1), dw = idx % (2 * PSWIN_WS - 1) - (PSWIN_WS - 1);
+    const float* p = summed + (size_t)h * 2 * TOK * TOK;
     float sb = 0.f, sa = 0.f;
-    for (int b = 0; b < n_blocks; ++b) {     // fixed order: bitwise reproducible
-        const float* p = partial + ((size_t)b * heads + h) * 2 * NBINS;
-        sb += p[idx];
-        sa += p[NBINS + idx];
+    for (int hj = 0; hj < PSWIN_WS; ++hj) {        // pairs with hi - hj = dh and wi - wj = dw
+        const int hi = hj + dh;
+        if (hi < 0 || hi >= PSWIN_WS) continue;
+        for (int wj = 0; wj < PSWIN_WS; ++wj) {
+            const int wi = wj + dw;
+            if (wi < 0 || wi >= PSWIN_WS) continue;
+            const int e = (hj * PSWIN_WS + wj) * TOK + hi * PSWIN_WS + wi;   // j * 49 + i
+            sb += p[e];
+            if (has_dist) sa += p[TOK * TOK + e];
+        }
     }
     dbeta[t] = sb;
     if (dalpha) dalpha[t] = sa;
@@ -655,7 +678,7 @@ extern "C" int pswin_attn_suggest_chunks(int n_windows, int n_bias_windows, int 
 }
 
 extern "C" int pswin_attn_bias_bwd_workspace(int heads) {
-    return heads > 0 ? BIAS_BWD_BLOCKS * heads * 2 * NBINS : PSWIN_ERR_ARG;
+    return heads > 0 ? (BIAS_BWD_BLOCKS + 1) * heads * 2 * TOK * TOK : PSWIN_ERR_ARG;
 }
 
 extern "C" int pswin_attn_bias_bwd(const float* dbias_ji, int n_tiles, int n_bias_windows, const float* dist,
@@ -665,9 +688,12 @@ extern "C" int pswin_attn_bias_bwd(const float* dbias_ji, int n_tiles, int n_bia
     PSWIN_CHECK_ARG(n_tiles % n_bias_windows == 0);
     PSWIN_CHECK_ARG(!dist || (n_dist > 0 && n_bias_windows % n_dist == 0));
     const int blocks = n_tiles < BIAS_BWD_BLOCKS ? n_tiles : BIAS_BWD_BLOCKS;
-    hipLaunchKernelGGL(bias_bwd_partial_kernel, dim3(blocks, heads), dim3(256), 0, (hipStream_t)stream, dbias_ji,
-                       n_tiles, n_bias_windows, dist, dist ? n_dist : 1, heads, workspace);
-    hipLaunchKernelGGL(bias_bwd_final_kernel, dim3((NBINS * heads + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-                       workspace, blocks, heads, dist ? dalpha : nullptr, dbeta);
+    hipLaunchKernelGGL(bias_bwd_partial_kernel, dim3(blocks, heads), dim3(BIAS_BWD_THREADS), 0, (hipStream_t)stream,
+                       dbias_ji, n_tiles, n_bias_windows, dist, dist ? n_dist : 1, heads, workspace);
+    const int ncol = heads * 2 * TOK * TOK;
+    float* summed = workspace + (size_t)BIAS_BWD_BLOCKS * ncol;
+    launch_colsum(workspace, blocks, ncol, summed, (hipStream_t)stream);
+    hipLaunchKernelGGL(bias_bwd_final_kernel, dim3((NBINS * heads + 63) / 64), dim3(64), 0, (hipStream_t)stream,
+                       summed, heads, dist != nullptr, dist ? dalpha : nullptr, dbeta);
     PSWIN_LAUNCH_RET();
 }

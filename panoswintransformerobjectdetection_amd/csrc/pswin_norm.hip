@@ -1,0 +1,385 @@
+// LayerNorm fused with the PanoSwin row movers (gfx950).
+//
+// In the reference every block does  norm1 -> cat uv -> roll/flip/cat -> pad -> window_partition  (HOT:503-513,
+// 64-75) and PatchMerging does  pad -> 4 strided slices -> cat -> norm  (HOT:563-574): a LayerNorm pass plus 4-7
+// full-tensor copies.  Here the normalisation happens inside the indexed row copy: one read of the source rows,
+// one write of the normalised rows in their destination layout (window slots / merged tokens), statistics kept
+// per source token for the backward pass.  The same kernel with an identity map is the plain LayerNorm used for
+// norm2 and the output norms, writing bf16 directly when the consumer is a bf16 GEMM.
+// HOT = mmdet/models/backbones/simple_panoswin_transformer.py of the reference.
+//
+// Mapping: a row of C elements is L lanes x up to 4 chunks of 4 elements (L = 2..64, a power of two, chosen on
+// the host so that L * 16 >= C); consecutive lanes read consecutive 16-byte chunks; row reductions are log2(L)
+// __shfl_xor steps.  Statistics and all arithmetic are fp32 regardless of the I/O dtype.
+#include "pswin_common.hpp"
+
+using namespace pswin;
+
+namespace {
+
+constexpr int THREADS = 256;
+
+template <int L>
+__device__ inline float row_sum(float v) {
+#pragma unroll
+    for (int off = L / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// MODE 0: out row (b, slot) <- source token map[slot] (or slot when map == nullptr), -1 = zero row.
+// MODE 1: PatchMerging: out row (b, i*W2 + j) <- concat of the 4 tokens (2i+dy, 2j+dx), zeros outside (H, W).
+struct RowSrc {
+    int mode;
+    const int32_t* map;   // MODE 0
+    int S, n_out;         // tokens per image, out rows per image
+    int H, W, W2;         // MODE 1
+};
+
+// source element offset (in elements, within the image) of chunk `ch` of out row r; -1 = zero
+template <int MODE>
+__device__ inline long long src_offset(const RowSrc& rs, int r, int ch, int C, int mode0_src) {
+    if constexpr (MODE == 0) {
+        return mode0_src < 0 ? -1 : (long long)mode0_src * C + 4 * ch;
+    } else {
+        const int cq = C / 4;                 // C is the OUTPUT width (4 * input channels): chunks per quarter = cq / 4
+        const int per_q = cq / 4;
+        const int k = ch / per_q, within = ch - k * per_q;
+        const int i = r / rs.W2, j = r - i * rs.W2;
+        const int yy = 2 * i + (k & 1), xx = 2 * j + (k >> 1);
+        if (yy >= rs.H || xx >= rs.W) return -1;
+        return ((long long)yy * rs.W + xx) * (C / 4) + 4 * within;
+    }
+}
+
+template <int MODE, int XDT, int YDT, int L, int NCH>
+__global__ __launch_bounds__(THREADS) void ln_fwd_kernel(const void* __restrict__ x, RowSrc rs,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float eps,
+                                                         void* __restrict__ y, float* __restrict__ mean,
+                                                         float* __restrict__ rstd, long long rows, int C) {
+    constexpr int RPB = THREADS / L;
+    const int lane = threadIdx.x % L;
+    const long long row = (long long)blockIdx.x * RPB + threadIdx.x / L;
+    if (row >= rows) return;
+    const int b = (int)(row / rs.n_out);
+    const int r = (int)(row - (long long)b * rs.n_out);
+    const int nchunks = C / 4;
+    const size_t img_in = (size_t)b * rs.S * (MODE == 0 ? C : C / 4);
+    int src0 = 0;
+    if constexpr (MODE == 0) src0 = rs.map ? rs.map[r] : r;
+    f32x4 v[NCH];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int ch = lane + k * L;
+        v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ch < nchunks) {
+            const long long off = src_offset<MODE>(rs, r, ch, C, src0);
+            if (off >= 0) v[k] = load4<XDT>(x, img_in + (size_t)off);
+            s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+        }
+    }
+    if (MODE == 0 && src0 < 0) {            // zero (padding) slot: stays zero, as F.pad after norm1 does (HOT:504-512)
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int ch = lane + k * L;
+            if (ch < nchunks) store4<YDT>(y, (size_t)row * C + 4 * (size_t)ch, f32x4{0.f, 0.f, 0.f, 0.f});
+        }
+        return;
+    }
+    const float mu = row_sum<L>(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int ch = lane + k * L;
+        if (ch < nchunks) {
+            const f32x4 d = v[k] - mu;
+            q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        }
+    }
+    const float rs_ = rsqrtf(row_sum<L>(q) / (float)C + eps);
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int ch = lane + k * L;
+        if (ch < nchunks) {
+            const f32x4 g4 = *reinterpret_cast<const f32x4*>(gamma + 4 * ch);
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(beta + 4 * ch);
+            store4<YDT>(y, (size_t)row * C + 4 * (size_t)ch, (v[k] - mu) * rs_ * g4 + b4);
+        }
+    }
+    if (lane == 0) {
+        // statistics live at the SOURCE token for MODE 0 (the backward pass walks tokens), at the out row for MODE 1
+        const size_t at = (MODE == 0) ? (size_t)b * rs.S + src0 : (size_t)row;
+        mean[at] = mu;
+        rstd[at] = rs_;
+    }
+}
+
+// Backward.  MODE 0 walks source tokens (b, t): dy row = dy[b][inv ? inv[t] : t].  MODE 1 walks merged rows and
+// scatters the 4 quarters of dx back to their tokens.  dgamma / dbeta: per-block partial sums, fixed order.
+template <int MODE, int DYDT, int XDT, int L, int NCH>
+__global__ __launch_bounds__(THREADS) void ln_bwd_kernel(const void* __restrict__ dy, const int32_t* __restrict__ inv,
+                                                         const void* __restrict__ x, RowSrc rs,
+                                                         const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd,
+                                                         const float* __restrict__ gamma, void* __restrict__ dx,
+                                                         float* __restrict__ part, long long rows, int C) {
+    constexpr int RPB = THREADS / L;
+    __shared__ float red[2][THREADS * 4];      // [row group][lane][4 elements] of one chunk column at a time
+    const int lane = threadIdx.x % L;
+    const int rsub = threadIdx.x / L;
+    const int nchunks = C / 4;
+    const int n_in = (MODE == 0) ? rs.S : rs.n_out;        // rows walked per image
+    f32x4 dg[NCH], db[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) dg[k] = db[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (long long row = (long long)blockIdx.x * RPB + rsub; row < rows; row += (long long)gridDim.x * RPB) {
+        const int b = (int)(row / n_in);
+        const int r = (int)(row - (long long)b * n_in);
+        size_t dy_row;
+        if constexpr (MODE == 0) dy_row = (size_t)b * rs.n_out + (inv ? inv[r] : r);
+        else dy_row = (size_t)row;
+        const size_t img_in = (size_t)b * rs.S * (MODE == 0 ? C : C / 4);
+        const float mu = mean[row], rs_ = rstd[row];
+        f32x4 xh[NCH], g[NCH];
+        long long offs[NCH];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int ch = lane + k * L;
+            xh[k] = g[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            offs[k] = -1;
+            if (ch < nchunks) {
+                offs[k] = src_offset<MODE>(rs, r, ch, C, r);
+                f32x4 xv = {0.f, 0.f, 0.f, 0.f};
+                if (offs[k] >= 0) xv = load4<XDT>(x, img_in + (size_t)offs[k]);
+                const f32x4 dyv = load4<DYDT>(dy, dy_row * C + 4 * (size_t)ch);
+                const f32x4 g4 = *reinterpret_cast<const f32x4*>(gamma + 4 * ch);
+                xh[k] = (xv - mu) * rs_;
+                g[k] = dyv * g4;
+                dg[k] = dg[k] + dyv * xh[k];
+                db[k] = db[k] + dyv;
+                s1 += (g[k][0] + g[k][1]) + (g[k][2] + g[k][3]);
+                s2 += (g[k][0] * xh[k][0] + g[k][1] * xh[k][1]) + (g[k][2] * xh[k][2] + g[k][3] * xh[k][3]);
+            }
+        }
+        s1 = row_sum<L>(s1) / (float)C;
+        s2 = row_sum<L>(s2) / (float)C;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int ch = lane + k * L;
+            if (ch < nchunks && offs[k] >= 0)
+                store4<XDT>(dx, img_in + (size_t)offs[k], (g[k] - s1 - xh[k] * s2) * rs_);
+        }
+    }
+    // block reduction of dgamma / dbeta over the RPB row groups (fixed order), then one partial row per block
+    float* outp = part + (size_t)blockIdx.x * 2 * C;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int ch = lane + k * L;
+        __syncthreads();
+        if (ch < nchunks) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                red[0][(rsub * L + lane) * 4 + e] = dg[k][e];
+                red[1][(rsub * L + lane) * 4 + e] = db[k][e];
+            }
+        }
+        __syncthreads();
+        if (rsub == 0 && ch < nchunks) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = 0.f, c = 0.f;
+                for (int q = 0; q < RPB; ++q) {
+                    a += red[0][(q * L + lane) * 4 + e];
+                    c += red[1][(q * L + lane) * 4 + e];
+                }
+                outp[4 * ch + e] = a;
+                outp[C + 4 * ch + e] = c;
+            }
+        }
+    }
+}
+
+// out_a[c] = sum_r part[r][c], out_b[c] = sum_r part[r][C + c]  (rows of 2C floats)
+__global__ void colsum2_kernel(const float* __restrict__ part, int R, int C, float* __restrict__ out_a,
+                               float* __restrict__ out_b) {
+    __shared__ float red[16][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int N = 2 * C;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < N) {
+        int r = rl;
+        for (; r + 16 < R; r += 32) {
+            s0 += part[(size_t)r * N + c];
+            s1 += part[(size_t)(r + 16) * N + c];
+        }
+        for (; r < R; r += 16) s0 += part[(size_t)r * N + c];
+    }
+    red[rl][cl] = s0 + s1;
+    __syncthreads();
+    if (rl == 0 && c < N) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += red[k][cl];
+        if (c < C) out_a[c] = s;
+        else out_b[c - C] = s;
+    }
+}
+
+inline void launch_colsum_2(const float* part, int R, int C, float* out_a, float* out_b, hipStream_t st) {
+    hipLaunchKernelGGL(colsum2_kernel, dim3((2 * C + 63) / 64), dim3(1024), 0, st, part, R, C, out_a, out_b);
+}
+
+// up to 4 chunks of 4 elements per lane (8 for rows wider than 1024 elements: PatchMerging of C >= 384)
+inline int pick_lanes(int C) {
+    int L = 2;
+    while (L * 16 < C && L < 64) L *= 2;
+    return L;
+}
+inline bool wide_row(int C) { return C > 1024; }
+constexpr int MAX_C = 2048;
+
+constexpr int BWD_MAX_BLOCKS = 512;
+
+inline int bwd_blocks(long long rows, int L) {
+    const int rpb = THREADS / L;
+    long long nb = (rows + rpb - 1) / rpb;
+    return (int)(nb < BWD_MAX_BLOCKS ? nb : BWD_MAX_BLOCKS);
+}
+
+template <int MODE, int XDT, int YDT>
+int launch_fwd(int L, const void* x, const RowSrc& rs, const float* gamma, const float* beta, float eps, void* y,
+               float* mean, float* rstd, long long rows, int C, hipStream_t st) {
+#define PSWIN_LN_FWD(LL)                                                                                          \
+    case LL: {                                                                                                    \
+        const int rpb = THREADS / LL;                                                                             \
+        hipLaunchKernelGGL((ln_fwd_kernel<MODE, XDT, YDT, LL, 4>), dim3((unsigned)((rows + rpb - 1) / rpb)),      \
+                           dim3(THREADS), 0, st, x, rs, gamma, beta, eps, y, mean, rstd, rows, C);                \
+        break;                                                                                                    \
+    }
+    if (wide_row(C)) {
+        hipLaunchKernelGGL((ln_fwd_kernel<MODE, XDT, YDT, 64, 8>), dim3((unsigned)((rows + 3) / 4)), dim3(THREADS), 0,
+                           st, x, rs, gamma, beta, eps, y, mean, rstd, rows, C);
+        PSWIN_LAUNCH_RET();
+    }
+    switch (L) {
+        PSWIN_LN_FWD(2) PSWIN_LN_FWD(4) PSWIN_LN_FWD(8) PSWIN_LN_FWD(16) PSWIN_LN_FWD(32) PSWIN_LN_FWD(64)
+        default: return PSWIN_ERR_ARG;
+    }
+#undef PSWIN_LN_FWD
+    PSWIN_LAUNCH_RET();
+}
+
+template <int MODE, int DYDT, int XDT>
+int launch_bwd(int L, const void* dy, const int32_t* inv, const void* x, const RowSrc& rs, const float* mean,
+               const float* rstd, const float* gamma, void* dx, float* part, long long rows, int C, int blocks,
+               hipStream_t st) {
+#define PSWIN_LN_BWD(LL)                                                                                          \
+    case LL:                                                                                                      \
+        hipLaunchKernelGGL((ln_bwd_kernel<MODE, DYDT, XDT, LL, 4>), dim3(blocks), dim3(THREADS), 0, st, dy, inv, \
+                           x, rs, mean, rstd, gamma, dx, part, rows, C);                                          \
+        break;
+    if (wide_row(C)) {
+        hipLaunchKernelGGL((ln_bwd_kernel<MODE, DYDT, XDT, 64, 8>), dim3(blocks), dim3(THREADS), 0, st, dy, inv, x, rs,
+                           mean, rstd, gamma, dx, part, rows, C);
+        PSWIN_LAUNCH_RET();
+    }
+    switch (L) {
+        PSWIN_LN_BWD(2) PSWIN_LN_BWD(4) PSWIN_LN_BWD(8) PSWIN_LN_BWD(16) PSWIN_LN_BWD(32) PSWIN_LN_BWD(64)
+        default: return PSWIN_ERR_ARG;
+    }
+#undef PSWIN_LN_BWD
+    PSWIN_LAUNCH_RET();
+}
+
+template <typename F>
+inline int dispatch2(int a, int b, F&& f) {
+    if (a == PSWIN_F32 && b == PSWIN_F32) return f(std::integral_constant<int, PSWIN_F32>(), std::integral_constant<int, PSWIN_F32>());
+    if (a == PSWIN_F32 && b == PSWIN_BF16) return f(std::integral_constant<int, PSWIN_F32>(), std::integral_constant<int, PSWIN_BF16>());
+    if (a == PSWIN_BF16 && b == PSWIN_F32) return f(std::integral_constant<int, PSWIN_BF16>(), std::integral_constant<int, PSWIN_F32>());
+    return f(std::integral_constant<int, PSWIN_BF16>(), std::integral_constant<int, PSWIN_BF16>());
+}
+
+}  // namespace
+
+extern "C" int pswin_ln_workspace(long long rows, int C) {
+    if (rows <= 0 || C <= 0 || C % 8) return PSWIN_ERR_ARG;
+    return bwd_blocks(rows, pick_lanes(C)) * 2 * C;
+}
+
+extern "C" int pswin_ln_gather_fwd(const void* x, int x_dtype, const int32_t* map, const float* gamma,
+                                   const float* beta, float eps, void* y, int y_dtype, float* mean, float* rstd, int B,
+                                   int S, int n_out, int C, void* stream) {
+    PSWIN_CHECK_ARG(x && gamma && beta && y && mean && rstd && B > 0 && S > 0 && n_out > 0);
+    PSWIN_CHECK_ARG(valid_dtype(x_dtype) && valid_dtype(y_dtype));
+    PSWIN_CHECK_ARG(C >= 8 && C % 8 == 0 && C <= MAX_C && aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta));
+    PSWIN_CHECK_ARG(map || n_out == S);
+    RowSrc rs = {0, map, S, n_out, 0, 0, 0};
+    const long long rows = (long long)B * n_out;
+    const int L = pick_lanes(C);
+    return dispatch2(x_dtype, y_dtype, [&](auto xd, auto yd) {
+        return launch_fwd<0, decltype(xd)::value, decltype(yd)::value>(L, x, rs, gamma, beta, eps, y, mean, rstd, rows,
+                                                                       C, (hipStream_t)stream);
+    });
+}
+
+extern "C" int pswin_ln_gather_bwd(const void* dy, int dy_dtype, const int32_t* inv, const void* x, int x_dtype,
+                                   const float* mean, const float* rstd, const float* gamma, void* dx, float* dgamma,
+                                   float* dbeta, float* workspace, int B, int S, int n_out, int C, void* stream) {
+    PSWIN_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && workspace && B > 0 && S > 0 && n_out > 0);
+    PSWIN_CHECK_ARG(valid_dtype(x_dtype) && valid_dtype(dy_dtype));
+    PSWIN_CHECK_ARG(C >= 8 && C % 8 == 0 && C <= MAX_C && aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(gamma));
+    PSWIN_CHECK_ARG(inv || n_out == S);
+    RowSrc rs = {0, nullptr, S, n_out, 0, 0, 0};
+    const long long rows = (long long)B * S;
+    const int L = pick_lanes(C);
+    const int blocks = bwd_blocks(rows, L);
+    int rc = dispatch2(dy_dtype, x_dtype, [&](auto dd, auto xd) {
+        return launch_bwd<0, decltype(dd)::value, decltype(xd)::value>(L, dy, inv, x, rs, mean, rstd, gamma, dx, workspace,
+                                                                       rows, C, blocks, (hipStream_t)stream);
+    });
+    if (rc) return rc;
+    // partial rows are [dgamma(C) | dbeta(C)]; the two outputs may live in different buffers -> two column sums
+    launch_colsum_2(workspace, blocks, C, dgamma, dbeta, (hipStream_t)stream);
+    PSWIN_LAUNCH_RET();
+}
+
+extern "C" int pswin_ln_patch_merge_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, float eps,
+                                        void* y, int y_dtype, float* mean, float* rstd, int B, int H, int W, int C,
+                                        void* stream) {
+    PSWIN_CHECK_ARG(x && gamma && beta && y && mean && rstd && B > 0 && H > 0 && W > 0);
+    PSWIN_CHECK_ARG(valid_dtype(x_dtype) && valid_dtype(y_dtype));
+    const int C4 = 4 * C;
+    PSWIN_CHECK_ARG(C >= 16 && C % 16 == 0 && C4 <= MAX_C && aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta));
+    const int H2 = (H + 1) / 2, W2 = (W + 1) / 2;
+    RowSrc rs = {1, nullptr, H * W, H2 * W2, H, W, W2};
+    const long long rows = (long long)B * H2 * W2;
+    const int L = pick_lanes(C4);
+    return dispatch2(x_dtype, y_dtype, [&](auto xd, auto yd) {
+        return launch_fwd<1, decltype(xd)::value, decltype(yd)::value>(L, x, rs, gamma, beta, eps, y, mean, rstd, rows,
+                                                                       C4, (hipStream_t)stream);
+    });
+}
+
+extern "C" int pswin_ln_patch_merge_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean,
+                                        const float* rstd, const float* gamma, void* dx, float* dgamma, float* dbeta,
+                                        float* workspace, int B, int H, int W, int C, void* stream) {
+    PSWIN_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && workspace && B > 0 && H > 0 && W > 0);
+    PSWIN_CHECK_ARG(valid_dtype(x_dtype) && valid_dtype(dy_dtype));
+    const int C4 = 4 * C;
+    PSWIN_CHECK_ARG(C >= 16 && C % 16 == 0 && C4 <= MAX_C && aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(gamma));
+    const int H2 = (H + 1) / 2, W2 = (W + 1) / 2;
+    RowSrc rs = {1, nullptr, H * W, H2 * W2, H, W, W2};
+    const long long rows = (long long)B * H2 * W2;
+    const int L = pick_lanes(C4);
+    const int blocks = bwd_blocks(rows, L);
+    int rc = dispatch2(dy_dtype, x_dtype, [&](auto dd, auto xd) {
+        return launch_bwd<1, decltype(dd)::value, decltype(xd)::value>(L, dy, nullptr, x, rs, mean, rstd, gamma, dx,
+                                                                       workspace, rows, C4, blocks, (hipStream_t)stream);
+    });
+    if (rc) return rc;
+    launch_colsum_2(workspace, blocks, C4, dgamma, dbeta, (hipStream_t)stream);
+    PSWIN_LAUNCH_RET();
+}

@@ -65,6 +65,7 @@ class GradReducer:
         self._pending = [b[2] for b in self.buckets]
         self._launched = [False] * len(self.buckets)
         self._handles = []
+        self.overlap = True          # launch buckets from backward hooks; set False to reduce everything in finish()
         self._use_avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params] if self.world > 1 else []
 
@@ -84,6 +85,8 @@ class GradReducer:
             self._handles.append((dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True), view))
 
     def _on_grad(self, p):
+        if not self.overlap:
+            return
         b = self._bucket_of[p]
         self._pending[b] -= 1
         if self._pending[b] == 0:

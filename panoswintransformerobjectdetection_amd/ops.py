@@ -182,6 +182,77 @@ def patch_merge_gather(x, H, W, out_dtype=None):
     return _PatchMergeGather.apply(x, H, W, out_dtype or x.dtype)
 
 
+class _LayerNormGather(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, wmap, inv, out_dtype):
+        B, S, C = x.shape
+        x = x.contiguous()
+        n_out = S if wmap is None else wmap.numel()
+        y = torch.empty(B, n_out, C, dtype=out_dtype, device=x.device)
+        mean = torch.empty(B, S, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        call("pswin_ln_gather_fwd", x, ptr(x), dtype_code(x), ptr(wmap), ptr(gamma), ptr(beta), float(eps), ptr(y),
+             dtype_code(y), ptr(mean), ptr(rstd), B, S, n_out, C,
+             algo_bytes=B * C * (min(S, n_out) * x.element_size() + n_out * y.element_size()))
+        ctx.save_for_backward(x, gamma, mean, rstd, inv)
+        ctx.n_out = n_out
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd, inv = ctx.saved_tensors
+        B, S, C = x.shape
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        ws = torch.empty(_lib.load().pswin_ln_workspace(B * S, C), dtype=torch.float32, device=x.device)
+        call("pswin_ln_gather_bwd", x, ptr(dy), dtype_code(dy), ptr(inv), ptr(x), dtype_code(x), ptr(mean), ptr(rstd),
+             ptr(gamma), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(ws), B, S, ctx.n_out, C,
+             algo_bytes=B * S * C * (dy.element_size() + 2 * x.element_size()))
+        return dx, dgamma, dbeta, None, None, None, None
+
+
+def layer_norm_gather(x, gamma, beta, eps, wmap=None, inv=None, out_dtype=None):
+    """LayerNorm over the last dim of x [B, S, C], written through a window map (norm1 + shift + pad + window
+    partition, HOT:503-513) or in place order (wmap=None: norm2 / output norms).  Padding slots are zero rows."""
+    return _LayerNormGather.apply(x, gamma, beta, eps, wmap, inv, out_dtype or x.dtype)
+
+
+class _LayerNormPatchMerge(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, H, W, out_dtype):
+        B, S, C = x.shape
+        x = x.contiguous()
+        H2, W2 = (H + 1) // 2, (W + 1) // 2
+        y = torch.empty(B, H2 * W2, 4 * C, dtype=out_dtype, device=x.device)
+        mean = torch.empty(B, H2 * W2, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        call("pswin_ln_patch_merge_fwd", x, ptr(x), dtype_code(x), ptr(gamma), ptr(beta), float(eps), ptr(y),
+             dtype_code(y), ptr(mean), ptr(rstd), B, H, W, C)
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.geom = (H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        B, S, C = x.shape
+        H, W = ctx.geom
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        rows = B * ((H + 1) // 2) * ((W + 1) // 2)
+        ws = torch.empty(_lib.load().pswin_ln_workspace(rows, 4 * C), dtype=torch.float32, device=x.device)
+        call("pswin_ln_patch_merge_bwd", x, ptr(dy), dtype_code(dy), ptr(x), dtype_code(x), ptr(mean), ptr(rstd),
+             ptr(gamma), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(ws), B, H, W, C)
+        return dx, dgamma, dbeta, None, None, None, None
+
+
+def layer_norm_patch_merge(x, gamma, beta, eps, H, W, out_dtype=None):
+    """PatchMerging's pad + 2x2 strided gather + concat + LayerNorm(4C) (HOT:563-574) in one kernel."""
+    return _LayerNormPatchMerge.apply(x, gamma, beta, eps, H, W, out_dtype or x.dtype)
+
+
 class _InterpRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, idx, wgt):

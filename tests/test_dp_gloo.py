@@ -1,0 +1,82 @@
+"""Data-parallel contract on CPU: 2 processes over gloo.  After finish() every rank holds the mean over ranks of the
+local gradients for every parameter (including parameters that got no gradient) and BatchNorm buffers stay local
+(reference: MMDistributedDataParallel with broadcast_buffers=False, mmdet/apis/train.py:91-99)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+
+class _Net(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv = nn.Conv2d(3, 8, 3, padding=1)
+        self.bn = nn.BatchNorm2d(8)
+        self.fc1 = nn.Linear(8, 16)
+        self.fc2 = nn.Linear(16, 4)
+        self.unused = nn.Parameter(torch.ones(5))        # never touched by forward
+
+    def forward(self, x):
+        y = torch.relu(self.bn(self.conv(x))).mean((2, 3))
+        return self.fc2(torch.tanh(self.fc1(y)))
+
+
+def _inputs(rank):
+    g = torch.Generator().manual_seed(100 + rank)
+    return torch.randn(4, 3, 8, 8, generator=g)
+
+
+def _local_grads(rank):
+    torch.manual_seed(0)
+    m = _Net()
+    m(_inputs(rank)).square().mean().backward()
+    return {k: (p.grad.clone() if p.grad is not None else torch.zeros_like(p)) for k, p in m.named_parameters()}, m
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from panoswintransformerobjectdetection_amd.dp import GradReducer, init_distributed
+    r, _, w = init_distributed(backend="gloo")
+    assert (r, w) == (rank, world)
+    torch.manual_seed(0 if rank == 0 else 77)            # different initial weights: broadcast must fix that
+    m = _Net()
+    red = GradReducer(m, bucket_mb=0.0005)               # tiny buckets -> several collectives
+    red.broadcast_parameters(m)
+    for _ in range(2):                                   # two steps: hooks / counters must re-arm
+        red.zero_grad()
+        m(_inputs(rank)).square().mean().backward()
+        red.finish()
+    q.put((rank, {k: p.grad.numpy().copy() for k, p in m.named_parameters()}, len(red.buckets),
+           m.bn.running_mean.numpy().copy()))                      # numpy: pickled by value, no fd passing
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_average():
+    world = 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    g0, _ = _local_grads(0)
+    g1, _ = _local_grads(1)
+    assert res[0][2] > 1                                  # more than one bucket was exercised
+    for k in g0:
+        want = (g0[k] + g1[k]) / 2
+        for r in range(world):
+            assert torch.allclose(torch.from_numpy(res[r][1][k]), want, rtol=1e-5, atol=1e-7), (k, r)
+    assert torch.equal(torch.from_numpy(res[0][1]["unused"]), torch.zeros(5))
+    assert not torch.allclose(torch.from_numpy(res[0][3]), torch.from_numpy(res[1][3]))   # BN stats stay per rank

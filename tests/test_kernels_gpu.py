@@ -115,6 +115,60 @@ def test_patch_merge(ops, H, W):
     assert torch.allclose(xd.grad.cpu(), xr.grad, rtol=1e-6, atol=1e-7)
 
 
+@pytest.mark.parametrize("C", [32, 96, 192, 768])
+@pytest.mark.parametrize("xdt,ydt", [(torch.float32, torch.float32), (torch.float32, torch.bfloat16),
+                                     (torch.bfloat16, torch.float32)])
+@pytest.mark.parametrize("use_map", [False, True])
+def test_layer_norm_gather(ops, C, xdt, ydt, use_map):
+    B, H, W = 2, 13, 25
+    x = (det_uniform((B, H * W, C), "ln:x", 2.0) + 0.3).to(xdt)
+    gamma, beta = det_uniform((C,), "ln:g", 0.5, 1.0), det_uniform((C,), "ln:b", 0.5)
+    xr = x.float().clone().requires_grad_(True)
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (C,), gr, br, 1e-5)
+    if use_map:
+        omap = po.pano_window_map(H, W, 3)[0]
+        ref = po.gather_windows(ref, omap)
+        wmap, inv, nW = ops.window_maps(True, H, W, 3, DEV)
+    else:
+        wmap = inv = None
+    xd = x.to(DEV).requires_grad_(True)
+    gd, bd = gamma.to(DEV).requires_grad_(True), beta.to(DEV).requires_grad_(True)
+    out = ops.layer_norm_gather(xd, gd, bd, 1e-5, wmap, inv, ydt)
+    assert out.dtype == ydt
+    tol = dict(rtol=1e-5, atol=2e-6) if ydt == torch.float32 else dict(rtol=1e-2, atol=1e-2)
+    assert torch.allclose(out.float().cpu(), ref, **tol)
+    gout = det_uniform(tuple(ref.shape), "ln:go").to(ydt)
+    (ref * gout.float()).sum().backward()
+    out.backward(gout.to(DEV))
+    gtol = dict(rtol=1e-4, atol=1e-5) if xdt == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    assert torch.allclose(xd.grad.float().cpu(), xr.grad, **gtol)
+    assert torch.allclose(gd.grad.cpu(), gr.grad, rtol=1e-4, atol=1e-4 * gr.grad.abs().max().item())
+    assert torch.allclose(bd.grad.cpu(), br.grad, rtol=1e-4, atol=1e-4 * br.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("H,W,C", [(5, 7, 32), (16, 32, 96), (8, 16, 384), (13, 25, 192)])
+@pytest.mark.parametrize("ydt", [torch.float32, torch.bfloat16])
+def test_layer_norm_patch_merge(ops, H, W, C, ydt):
+    B = 2
+    x = det_uniform((B, H * W, C), "lnpm:x", 2.0) + 0.1
+    gamma, beta = det_uniform((4 * C,), "lnpm:g", 0.5, 1.0), det_uniform((4 * C,), "lnpm:b", 0.5)
+    pm = po.patch_merge_map(H, W)
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    gat = (xr[:, pm.clamp(min=0).reshape(-1), :] * (pm.reshape(-1) >= 0).float()[None, :, None]).reshape(B, -1, 4 * C)
+    ref = F.layer_norm(gat, (4 * C,), gr, br, 1e-5)
+    xd, gd, bd = [t.to(DEV).requires_grad_(True) for t in (x, gamma, beta)]
+    out = ops.layer_norm_patch_merge(xd, gd, bd, 1e-5, H, W, ydt)
+    tol = dict(rtol=1e-5, atol=2e-6) if ydt == torch.float32 else dict(rtol=1e-2, atol=1e-2)
+    assert torch.allclose(out.float().cpu(), ref, **tol)
+    gout = det_uniform(tuple(ref.shape), "lnpm:go").to(ydt)
+    (ref * gout.float()).sum().backward()
+    out.backward(gout.to(DEV))
+    assert torch.allclose(xd.grad.cpu(), xr.grad, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(gd.grad.cpu(), gr.grad, rtol=1e-4, atol=1e-4 * gr.grad.abs().max().item())
+    assert torch.allclose(bd.grad.cpu(), br.grad, rtol=1e-4, atol=1e-4 * br.grad.abs().max().item())
+
+
 @pytest.mark.parametrize("H,W", [(14, 28), (16, 32), (4, 8)])
 def test_pitch_static_resampling(ops, H, W):
     """interp_rows with the host-built tap tables == the oracle's two F.grid_sample calls."""
