@@ -89,7 +89,7 @@ def main():
     model = SimplePanoSwinTransformer(**TCFG, compute_dtype=cd)
     model.init_weights(None)
     model = model.to(dev).train()
-    reducer = GradReducer(model, bucket_mb=args.bucket_mb)
+    reducer = GradReducer(model, bucket_mb=args.bucket_mb, pack=not args.eager)
     reducer.broadcast_parameters(model)
     opt = torch.optim.AdamW(model.parameters(), lr=1e-4, betas=(0.9, 0.999), weight_decay=0.05, fused=True,
                             capturable=not args.eager)
@@ -102,6 +102,8 @@ def main():
         outs = model(x)
         loss = sum(o.float().mean() for o in outs)
         loss.backward()
+        if reducer.pack:
+            reducer.pack_grads()
         return loss
 
     def eager_step():
@@ -116,9 +118,8 @@ def main():
         # One hipGraph for forward+backward, one for the optimizer; the RCCL all-reduce of the flat gradient buffer
         # runs between the two replays (N > 1), so collectives are never part of a captured graph.
         from panoswintransformerobjectdetection_amd.graph import GraphedCallable
-        reducer.overlap = False                  # hooks must not launch collectives during capture
         g_fb = GraphedCallable(fwd_bwd, warmup=2)
-        g_opt = GraphedCallable(opt.step, warmup=1)
+        g_opt = GraphedCallable(opt.step, warmup=1, stream=g_fb.stream)
 
         def step():
             loss = g_fb()
@@ -144,8 +145,14 @@ def main():
     if not args.eager:
         # Nodes of a replayed graph cannot be bracketed by host-recorded events, so the per-kernel HIP-event timing
         # runs on eager steps of the same model / batch right after the timed region (same kernels, shapes, data).
+        # An eager step is host-bound (the GPU drains its queue and idles between launches), which would put idle time
+        # inside the event pairs.  A spin kernel in front of every step lets the host enqueue the whole step first,
+        # so the kernels then run back to back exactly as they do inside the graph.
+        spin = 200_000_000 if hasattr(torch.cuda, "_sleep") else 0        # ~80-100 ms of spinning at 2-2.4 GHz
         _lib.enable_timing(TIMED)
         for _ in range(args.kernel_steps):
+            if spin:
+                torch.cuda._sleep(spin)
             eager_step()
     kern = _lib.disable_timing()
     ksteps = args.steps if args.eager else args.kernel_steps

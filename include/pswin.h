@@ -153,6 +153,12 @@ int pswin_patch_merge_gather(const void* x, int x_dtype, void* out, int out_dtyp
 int pswin_patch_merge_scatter(const void* dout, int out_dtype, void* dx, int x_dtype, int B, int H, int W, int C,
                               void* stream);
 
+/* Column sums of a row-major [M, N] matrix in fp32: out[n] = sum_m x[m][n] (fixed summation order).  The bias
+ * gradient of every Linear on the path (autograd of nn.Linear, HOT:50-52, 236, 323) and the reduction of split-K
+ * weight-gradient partials.  N % 8 == 0; workspace: f32, pswin_colsum_workspace(M, N, dtype) elements. */
+int pswin_colsum_workspace(long long M, int N, int dtype);
+int pswin_colsum(const void* x, int dtype, long long M, int N, float* out, float* workspace, void* stream);
+
 /* Static 4-tap row interpolation (the two F.grid_sample calls of PitchAttentionModule.get_rotated,
  * HOT:1038, 1090, with input-independent grids; lzx/pano_rotate.py:169-187):
  * out[b][p][:] = sum_k wgt[p][k] * x[b][idx[p][k]][:]   x: [B, S, C] f32, out: [B, P, C] f32,
@@ -170,54 +176,57 @@ int pswin_interp_rows_adjoint(const float* dout, const int32_t* idx, const float
  * proj Linear layers, and PitchAttentionModule._attention (HOT:1206-1237) between q/k/v_linear and proj.
  * ---------------------------------------------------------------------------------------------- */
 
-/* Additive score bias, shared by every image of the batch (BasicWindowAttention._sphere_bias, HOT:241-272,
- * plus the shifted-window mask add of HOT:295-303), laid out as MFMA accumulator tiles:
- *   bias(wb,h,i,j) = (dist ? dist[wb % n_dist][i][j] * alpha[idx(i,j)][h] : 0) + beta[idx(i,j)][h]
- *                    + (mask ? mask[wb % n_mask][i][j] : 0)            for i, j < 49
- *   idx(i,j) = (i/7 - j/7 + 6) * 13 + (i%7 - j%7 + 6)   (make_relative_position_index, HOT:95-129)
- *   bias(.,.,i,j>=49) = -inf (padded keys never receive weight), bias(.,.,i>=49,j<49) = 0.
- * bias_ij: f32 [n_bias_windows, heads, 64(i), 64(j)]; bias_ji: the same values transposed to [.., 64(j), 64(i)]
- * (consumed by the backward kernel), may be NULL.
- * dist: f32 [n_dist, 49, 49] or NULL (planar mode); alpha: f32 [169, heads] (ignored when dist is NULL);
- * beta: f32 [169, heads]; mask: f32 [n_mask, 49, 49] or NULL.
+/* Score bias of window n, head h (BasicWindowAttention._sphere_bias, HOT:241-272, plus the shifted-window mask add
+ * of HOT:295-303), evaluated inside the attention kernels once per (bias window, head) and shared by every image
+ * of the batch (window n uses bias window n % n_bias_windows):
+ *   bias(i,j) = (dist ? dist[wb % n_dist](i,j) * alpha[idx(i,j)][h] : 0) + beta[idx(i,j)][h]
+ *               + (mask ? mask[wb % n_mask](i,j) : 0)
+ *   idx(i,j)  = (i/7 - j/7 + 6) * 13 + (i%7 - j%7 + 6)         (make_relative_position_index, HOT:95-129)
+ * dist / mask are passed as zero-padded 64 x 64 TILES (pswin_attn_pad_tiles): the forward kernel reads tile[i][j],
+ * the backward kernel reads the TRANSPOSED tile[j][i] (for the symmetric self-attention tables both are the same
+ * buffer).  alpha (ignored when dist is NULL: planar mode, HOT:257-258), beta: f32 [169, heads].
  * n_bias_windows must be a multiple of n_dist and of n_mask. */
-int pswin_attn_bias_build(const float* dist, int n_dist, const float* alpha, const float* beta, const float* mask,
-                          int n_mask, int n_bias_windows, int heads, float* bias_ij, float* bias_ji,
-                          void* stream);
 
-/* out[n][i][h*32 + d] = sum_j softmax_j(scale * q[n][i][h][:] . k[n][j][h][:] + bias(n % nb, h, i, j)) v[n][j][h][d]
+/* [n, 49, 49] -> zero-padded [n, 64, 64] tiles, transposed when `transpose` != 0. */
+int pswin_attn_pad_tiles(const float* src, int n, int transpose, float* dst, void* stream);
+
+/* out[n][i][h*32 + d] = sum_j softmax_j(scale * q[n][i][h][:] . k[n][j][h][:] + bias(i, j)) v[n][j][h][d]
  * q, k, v: element pointers to head 0 of token 0 of window 0; token rows are ld_qkv elements apart, heads 32
  * elements apart (one fused [n*49, 3C] qkv buffer: q = base, k = base + C, v = base + 2C, ld_qkv = 3C).
  * out: [n_windows*49, ld_out]; lse: f32 [n_windows, heads, 64] = log-sum-exp of every score row (+inf in rows
- * >= 49), kept for the backward pass.  n_windows % n_bias_windows == 0, window n uses bias tile n % n_bias_windows.
+ * >= 49), kept for the backward pass.  n_windows % n_bias_windows == 0.
+ * n_chunks: how many work items share one bias window's batch loop (0 = pswin_attn_suggest_chunks; otherwise a
+ * divisor of n_windows / n_bias_windows).
  * dtype: q, k, v, out all PSWIN_F32 (exact-f32 MFMA) or all PSWIN_BF16 (bf16 MFMA, f32 softmax/accumulate).
  * Pointers 16-byte aligned, ld_qkv % 8 == 0, ld_out % 8 == 0. */
-int pswin_attn_fwd(const void* q, const void* k, const void* v, int ld_qkv, const float* bias_ij, void* out,
-                   int ld_out, float* lse, int n_windows, int n_bias_windows, int heads, float scale, int dtype,
+int pswin_attn_fwd(const void* q, const void* k, const void* v, int ld_qkv, const float* dist_tiles, int n_dist,
+                   const float* alpha, const float* beta, const float* mask_tiles, int n_mask, void* out, int ld_out,
+                   float* lse, int n_chunks, int n_windows, int n_bias_windows, int heads, float scale, int dtype,
                    void* stream);
 
+/* Host helper: the number of batch-loop chunks the library would pick for this geometry (enough independent
+ * waves to fill the chip while keeping the per-work-item bias reuse long), for the forward (backward = 0) or the
+ * backward (backward = 1) kernel.  Returns the chunk count (>= 1) or PSWIN_ERR_ARG. */
+int pswin_attn_suggest_chunks(int n_windows, int n_bias_windows, int heads, int backward);
+
 /* Gradients of pswin_attn_fwd.  dq, dk, dv use the q/k/v addressing (ld_dqkv), dout the out addressing.
- * dbias_ji: f32 [n_chunks, n_bias_windows, heads, 64(j), 64(i)] receives, per chunk of the batch loop, the sum
- * over that chunk's windows of dScore (the gradient w.r.t. bias, transposed like bias_ji); n_chunks is chosen by
- * the caller (1 <= n_chunks <= n_windows / n_bias_windows, must divide it).  May be NULL when the bias needs no
- * gradient (n_chunks is still used to split the batch loop). */
-int pswin_attn_bwd(const void* q, const void* k, const void* v, int ld_qkv, const float* bias_ji, const void* dout,
-                   int ld_out, const float* lse, void* dq, void* dk, void* dv, int ld_dqkv, float* dbias_ji,
+ * dist_tiles_t / mask_tiles_t: the TRANSPOSED tiles.  n_chunks splits the batch loop (1 <= n_chunks <=
+ * n_windows / n_bias_windows, must divide it).
+ * dscore_sum: f32 [n_chunks * n_bias_windows, heads, 64(j), 64(i)] or NULL: per work item, the sum over its images
+ * of dScore (= the gradient w.r.t. the bias), transposed like the backward tiles; input of pswin_attn_table_grads. */
+int pswin_attn_bwd(const void* q, const void* k, const void* v, int ld_qkv, const float* dist_tiles_t, int n_dist,
+                   const float* alpha, const float* beta, const float* mask_tiles_t, int n_mask, const void* dout,
+                   int ld_out, const float* lse, void* dq, void* dk, void* dv, int ld_dqkv, float* dscore_sum,
                    int n_chunks, int n_windows, int n_bias_windows, int heads, float scale, int dtype, void* stream);
 
-/* Host helper: the number of batch-loop chunks pswin_attn_fwd uses internally for this geometry (enough
- * independent waves to fill the chip while keeping the per-tile bias reuse long); a good n_chunks for
- * pswin_attn_bwd.  Returns the chunk count (>= 1) or PSWIN_ERR_ARG. */
-int pswin_attn_suggest_chunks(int n_windows, int n_bias_windows, int heads);
-
-/* Reduce dbias_ji tiles into the table gradients (adjoint of pswin_attn_bias_build w.r.t. alpha, beta):
- *   dbeta[t][h]  = sum over tiles, (i,j) with idx(i,j) = t of g ;  dalpha[t][h] = the same sum of g * dist.
- * dbias_ji: f32 [n_tiles, heads, 64, 64] with tile x belonging to bias window x % n_bias_windows;
- * dalpha (may be NULL when dist is NULL), dbeta: f32 [169, heads], overwritten.
- * workspace: f32, at least pswin_attn_bias_bwd_workspace(heads) elements. */
-int pswin_attn_bias_bwd_workspace(int heads);
-int pswin_attn_bias_bwd(const float* dbias_ji, int n_tiles, int n_bias_windows, const float* dist, int n_dist,
-                        int heads, float* dalpha, float* dbeta, float* workspace, void* stream);
+/* Table gradients (adjoint of the bias w.r.t. alpha, beta), in a fixed summation order:
+ *   dbeta[t][h] = sum over tiles and (i,j) with idx(i,j) = t of g ;  dalpha[t][h] = the same sum of g * dist(i,j).
+ * dscore_sum: the n_tiles = n_chunks * n_bias_windows tiles written by pswin_attn_bwd; dist_tiles_t as there (NULL in
+ * planar mode: dalpha untouched); dalpha, dbeta: f32 [169, heads], overwritten.
+ * workspace: f32, pswin_attn_table_grads_workspace(heads) elements. */
+int pswin_attn_table_grads_workspace(int heads);
+int pswin_attn_table_grads(const float* dscore_sum, int n_tiles, int n_bias_windows, const float* dist_tiles_t,
+                           int n_dist, int heads, float* dalpha, float* dbeta, float* workspace, void* stream);
 
 #ifdef __cplusplus
 }

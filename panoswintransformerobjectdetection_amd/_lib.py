@@ -35,14 +35,17 @@ _PROTOTYPES = {
     "pswin_ln_patch_merge_bwd": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "pswin_patch_merge_gather": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "pswin_patch_merge_scatter": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
+    "pswin_colsum_workspace": [ctypes.c_longlong, _i, _i],
+    "pswin_colsum": [_vp, _i, ctypes.c_longlong, _i, _vp, _vp, _vp],
     "pswin_interp_rows": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "pswin_interp_rows_adjoint": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
-    "pswin_attn_bias_build": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
-    "pswin_attn_fwd": [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _f, _i, _vp],
-    "pswin_attn_bwd": [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _f, _i, _vp],
-    "pswin_attn_suggest_chunks": [_i, _i, _i],
-    "pswin_attn_bias_bwd_workspace": [_i],
-    "pswin_attn_bias_bwd": [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp],
+    "pswin_attn_pad_tiles": [_vp, _i, _i, _vp, _vp],
+    "pswin_attn_fwd": [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _f, _i, _vp],
+    "pswin_attn_suggest_chunks": [_i, _i, _i, _i],
+    "pswin_attn_bwd": [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp,
+                       _i, _i, _i, _i, _f, _i, _vp],
+    "pswin_attn_table_grads_workspace": [_i],
+    "pswin_attn_table_grads": [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp],
 }
 
 _lib = None

@@ -130,10 +130,10 @@ class _LinearSplitK(torch.autograd.Function):
         ch = _pick_split(M, -(-N // 64) * -(-K // 64))
         if ch > 1:
             part = torch.bmm(dy.view(ch, M // ch, N).transpose(1, 2), x.view(ch, M // ch, K))
-            dw = part.sum(0, dtype=torch.float32)
+            dw = ops.colsum(part.view(ch, N * K)).view(N, K)
         else:
             dw = (dy.t() @ x).float()
-        db = dy.sum(0, dtype=torch.float32) if ctx.has_bias else None
+        db = ops.colsum(dy) if ctx.has_bias else None
         return dx, dw, db
 
 
@@ -167,10 +167,10 @@ class PanoSwinTransformerBlock(nn.Module, DoubleModeModule):
         pano = bool(self.pano_mode)
         wmap, inv, nW = ops.window_maps(pano, H, W, self.shift_size, dev)
         if pano:
-            dist, mask = ops.window_dist(H, W, self.shift_size, dev), None       # no mask in pano mode (HOT:698-699)
+            dist, mask = ops.window_dist_tiles(H, W, self.shift_size, dev), None  # no mask in pano mode (HOT:698-699)
         else:
             dist = None
-            mask = ops.planar_mask(H, W, self.shift_size, dev) if self.shift_size else None   # HOT:474
+            mask = ops.planar_mask_tiles(H, W, self.shift_size, dev) if self.shift_size else None   # HOT:474
         a = self.attn
         n1 = self.norm1                                                           # norm1 + shift + pad + partition
         win = ops.layer_norm_gather(x, n1.weight, n1.bias, n1.eps, wmap, inv, cd)  # [B, nW*49, C]
@@ -215,7 +215,7 @@ class PitchAttentionModule(WindowAttention):
             uv4 = torch.cat([uv, torch.zeros_like(uv)], -1)[None].contiguous()           # rows of 4 for the row kernel
             uv_rot = ops.interp_rows(ops.interp_rows(uv4, t["idx1"], t["w1"]), t["idx2"], t["w2"])[0, :, :2]
             uv_win = ops.gather_uv(uv, wmap)
-            t["dist"] = ops.haversine_windows(uv_win.view(nW, WTOK, 2), uv_rot.contiguous().view(nW, WTOK, 2))
+            t["dist"] = ops.Tiles(ops.haversine_windows(uv_win.view(nW, WTOK, 2), uv_rot.contiguous().view(nW, WTOK, 2)))
             self._static[key] = t
         return self._static[key]
 
@@ -293,6 +293,24 @@ class BasicLayer(nn.Module, DoubleModeModule):
         return x, H, W, self.downsample(x, H, W, cd), (H + 1) // 2, (W + 1) // 2
 
 
+class _ChannelBias(torch.autograd.Function):
+    """y + bias over the channel dim of a channels-last NCHW tensor; the bias gradient is a column sum over the
+    [N*H*W, C] row view (pswin_colsum).  Keeps the convolution bias out of MIOpen's ConvolutionBackwardBias, whose
+    result is garbage (1e34) from the second replay on when the step is captured in a hipGraph (ROCm 7.2)."""
+
+    @staticmethod
+    def forward(ctx, y, bias):
+        return y + bias.to(y.dtype).view(1, -1, 1, 1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        C = dy.shape[1]
+        rows = dy.permute(0, 2, 3, 1).reshape(-1, C)           # a view for channels-last gradients
+        if C % 8:
+            return dy, rows.sum(0, dtype=torch.float32)
+        return dy, ops.colsum(rows)
+
+
 class PatchEmbed(nn.Module):
     """HOT:727-773 (convolutions through MIOpen; channels-last so that the token layout needs no transpose)."""
 
@@ -315,7 +333,12 @@ class PatchEmbed(nn.Module):
         if H % ph:
             x = F.pad(x, (0, 0, 0, ph - H % ph))
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=(cd == torch.bfloat16)):
-            x = self.proj(x.contiguous(memory_format=torch.channels_last))      # bf16: MIOpen NHWC bf16 convolutions
+            x = x.contiguous(memory_format=torch.channels_last)                 # bf16: MIOpen NHWC bf16 convolutions
+            for mod in self.proj:
+                if isinstance(mod, nn.Conv2d):
+                    x = _ChannelBias.apply(F.conv2d(x, mod.weight, None, mod.stride, mod.padding), mod.bias)
+                else:
+                    x = mod(x)
         B, C, Wh, Ww = x.shape
         tok = x.permute(0, 2, 3, 1).reshape(B, Wh * Ww, C)          # free for a channels-last tensor
         if self.norm is not None:                                    # reads bf16 or fp32, writes the fp32 residual stream

@@ -9,15 +9,22 @@
 //
 // Design (CDNA4, wave64):
 //   * 49 tokens are padded to 64 = 4 MFMA tiles of 16.  One wave per (bias window wb, head h) work item;
-//     the wave loops over the images of the batch that share that bias tile (window n = rep*nb + wb), so the
-//     bias is read once per work item and stays in 64 VGPRs as the MFMA C operand: S + bias costs nothing.
-//   * the bias tile carries -inf in the padded key columns, so padding needs no masking code.
+//     the wave loops over the images of the batch that share that bias (window n = rep*nb + wb).  The bias
+//     d(i,j) * alpha[idx(i,j)][h] + beta[idx(i,j)][h] (+ mask) is computed ONCE per work item from the cached
+//     distance tile and the two 169-entry table columns (staged in LDS), stays in 64 VGPRs and enters every
+//     score tile as the MFMA C operand: S + bias costs nothing per image.
+//   * padded key columns get bias -inf, so padding needs no masking code.
+//   * the next image's Q/K/V(/dO) fragments are requested from HBM before the current image's softmax / PV
+//     (forward) resp. at the top of the iteration into a second register set (backward): one wave keeps
+//     9-12 KB of loads in flight at all times.
 //   * forward computes S^T = K.Q^T (key on the accumulator row, query on the lane): a score row lives in one
 //     lane (+ its 3 partner lanes), softmax needs 2 cross-lane steps, and P is already the B operand of
 //     O^T = V^T.P^T.  V^T comes from LDS through ds_read_b64_tr_b16 (bf16) / scalar LDS reads (f32).
 //   * backward computes S = Q.K^T and dP = dO.V^T with the query on the accumulator row: P and dS are then
 //     already the B operands of dV^T = dO^T.P and dK^T = Q^T.dS; only dS crosses LDS once (for dQ).
-//     dBias = sum over the batch loop of dS stays in 64 VGPRs and is written once per work item.
+//     sum over the batch loop of dS (the bias gradient) stays in 64 VGPRs; at the end of the work item it is
+//     binned into the 169 table entries (x 1 for beta, x d for alpha) with LDS atomics and written as one
+//     1.4 KB partial per work item; a fixed-order column sum over the work items finishes dalpha / dbeta.
 //   * dtype f32 uses the exact-f32 MFMA (v_mfma_f32_16x16x4_f32, k-ordered fmaf chain) so the f32 path
 //     matches the PyTorch reference to summation order; dtype bf16 uses v_mfma_f32_16x16x32_bf16 with f32
 //     softmax / accumulation.
@@ -194,41 +201,120 @@ __device__ inline void store_quad(void* base, size_t off, f32x4 q) {
     store4<DT>(base, off, q);
 }
 
+// Cross-lane reductions on the VALU (no ds_bpermute round trips through the LDS crossbar).
+// v_permlane16_swap(a, b) exchanges the odd 16-lane rows of a with the even rows of b; with a = b = v the two results
+// are [r0 r0 r2 r2] and [r1 r1 r3 r3], so combining them reduces over lane ^ 16.  v_permlane32_swap likewise for ^ 32.
+// Written as inline asm: hipcc (ROCm 7.2) deletes the combine after __builtin_amdgcn_permlaneNN_swap(x, x) (it
+// treats the two results as equal; seen in the ISA, outputs wrong by the missing reduction).  The s_nop covers the
+// VALU-write -> permlane-read hazard the compiler would otherwise pad itself.
+__device__ inline void swap16(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+__device__ inline void swap32(float& a, float& b) { asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
 __device__ inline float group_max(float v) {   // across the 4 lane groups (lanes c, c+16, c+32, c+48)
-    v = fmaxf(v, __shfl_xor(v, 16));
-    return fmaxf(v, __shfl_xor(v, 32));
+    float a = v, b = v;
+    swap16(a, b);
+    a = fmaxf(a, b);
+    b = a;
+    swap32(a, b);
+    return fmaxf(a, b);
 }
 __device__ inline float group_sum(float v) {
-    v += __shfl_xor(v, 16);
-    return v + __shfl_xor(v, 32);
+    float a = v, b = v;
+    swap16(a, b);
+    a = a + b;
+    b = a;
+    swap32(a, b);
+    return a + b;
 }
-__device__ inline float row16_sum(float v) {   // across the 16 lanes of a group
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
-    return v + __shfl_xor(v, 8);
+template <int CTRL>
+__device__ inline float dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ inline float row16_sum(float v) {   // across the 16 lanes of a group: quad xor 1, xor 2, then mirrors
+    v = dpp_add<0xB1>(v);    // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E>(v);    // quad_perm [2,3,0,1]
+    v = dpp_add<0x141>(v);   // row_half_mirror: the other quad of the 8 (all 4 lanes of a quad agree by now)
+    return dpp_add<0x140>(v);   // row_mirror: the other half of the 16
 }
 
 struct AttnArgs {
     const void *q, *k, *v;
-    const float* bias;      // fwd: bias_ij, bwd: bias_ji
-    void* out;              // fwd: out ; bwd: unused
+    const float* dist;      // fwd: [n_dist][64 i][64 j] ; bwd: transposed tiles [n_dist][64 j][64 i] ; may be null
+    const float* mask;      // same layouts, additive mask tiles ; may be null
+    const float* alpha;     // [169][heads] (read only when dist != null)
+    const float* beta;      // [169][heads]
+    void* out;              // fwd
     const void* dout;       // bwd
     float* lse;             // fwd: written ; bwd: read
     void *dq, *dk, *dv;     // bwd
-    float* dbias;           // bwd (may be null)
+    float* dtab;            // bwd: [n_items][64 j][64 i] sums of dS over the item's images, or null
+    int n_dist, n_mask;
     int ld_qkv, ld_out, ld_dqkv;
     int nb, heads, reps_per_chunk, n_items;
     float scale;
+};
+
+constexpr int NBINS = (2 * PSWIN_WS - 1) * (2 * PSWIN_WS - 1);   // 169
+constexpr int TABP = 176;                                         // padded table length
+
+__device__ inline int rel_a(int i) { return 13 * (i / PSWIN_WS) + i % PSWIN_WS + 84; }   // idx(i, j) = rel_a(i) - rel_b(j)
+__device__ inline int rel_b(int j) { return 13 * (j / PSWIN_WS) + j % PSWIN_WS; }
+
+// stage column h of the [169][heads] tables into this wave's LDS
+__device__ inline void load_tables(const AttnArgs& a, int h, int lane, float* tab_a, float* tab_b) {
+    for (int t = lane; t < NBINS; t += 64) {
+        tab_b[t] = a.beta[t * a.heads + h];
+        tab_a[t] = a.dist ? a.alpha[t * a.heads + h] : 0.f;
+    }
+}
+
+// bias quad for query index base qi (4 consecutive when QUERY_ON_REGS) / key index base kj.
+// QUERY_ON_REGS = false (forward):  i = qi fixed, j = kj + e          tile row = i, quad along j
+// QUERY_ON_REGS = true  (backward): i = qi + e,   j = kj fixed        tile row = j (transposed tiles), quad along i
+template <bool QUERY_ON_REGS>
+__device__ inline f32x4 bias_quad(const float* dtile, const float* mtile, const float* tab_a, const float* tab_b,
+                                  int qi, int kj) {
+    const int row = QUERY_ON_REGS ? kj : qi, col = QUERY_ON_REGS ? qi : kj;
+    f32x4 d4 = {0.f, 0.f, 0.f, 0.f}, m4 = {0.f, 0.f, 0.f, 0.f};
+    if (dtile) d4 = *reinterpret_cast<const f32x4*>(dtile + row * PADT + col);
+    if (mtile) m4 = *reinterpret_cast<const f32x4*>(mtile + row * PADT + col);
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int i = QUERY_ON_REGS ? qi + e : qi, j = QUERY_ON_REGS ? kj : kj + e;
+        float val;
+        if (j >= TOK) {
+            val = -INFINITY;                    // padded key: never receives weight
+        } else if (i >= TOK) {
+            val = 0.f;                          // padded query row: discarded
+        } else {
+            const int idx = rel_a(i) - rel_b(j);
+            // same rounding sequence as the reference: (d * alpha + beta) [+ mask]   (HOT:255-256, 294, 301)
+            val = tab_b[idx];
+            if (dtile) val = __fadd_rn(__fmul_rn(d4[e], tab_a[idx]), val);
+            if (mtile) val = __fadd_rn(val, m4[e]);
+        }
+        r[e] = val;
+    }
+    return r;
+}
+
+template <int DT>
+struct Tiles3 {
+    Frag<DT> q[4], k[4], v[4];
+};
+template <int DT>
+struct Tiles4 {
+    Frag<DT> q[4], k[4], v[4], d[4];
 };
 
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
 template <int DT, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void attn_fwd_kernel(AttnArgs a) {
+__global__ __launch_bounds__(64 * WAVES, (DT == PSWIN_BF16 ? 2 : 1)) void attn_fwd_kernel(AttnArgs a) {   // bf16: <= 256 VGPRs
     using VImg = LdsImg<DT, HD>;
-    __shared__ __attribute__((aligned(16))) char smem[WAVES * VImg::BYTES];
+    constexpr int WBYTES = VImg::BYTES + 2 * TABP * 4;
+    __shared__ __attribute__((aligned(16))) char smem[WAVES * WBYTES];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c = lane & 15, g = lane >> 4;
     const int item = blockIdx.x * WAVES + wave;
@@ -236,33 +322,54 @@ __global__ __launch_bounds__(64 * WAVES) void attn_fwd_kernel(AttnArgs a) {
     const int h = item % a.heads;
     const int wb = (item / a.heads) % a.nb;
     const int chunk = item / (a.heads * a.nb);
-    char* vimg = smem + wave * VImg::BYTES;
+    char* vimg = smem + wave * WBYTES;
+    float* tab_a = reinterpret_cast<float*>(vimg + VImg::BYTES);
+    float* tab_b = tab_a + TABP;
 
-    // bias tile of (wb, h): query on the lane, 4 consecutive keys per quad
+    auto load_tiles = [&](int r, Tiles3<DT>& t) {
+        const size_t row0 = ((size_t)(chunk * a.reps_per_chunk + r) * a.nb + wb) * TOK;
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const int row = 16 * tt + c;
+            const bool ok = row < TOK;
+            const size_t off = (row0 + row) * (size_t)a.ld_qkv + h * HD + 8 * g;
+            t.q[tt] = load_frag<DT>(a.q, off, ok);
+            t.k[tt] = load_frag<DT>(a.k, off, ok);
+            t.v[tt] = load_frag<DT>(a.v, off, ok);
+        }
+    };
+    Tiles3<DT> cur;
+    load_tiles(0, cur);              // in flight while the bias is being built
+
+    load_tables(a, h, lane, tab_a, tab_b);
+    __builtin_amdgcn_wave_barrier();
+    // bias tile of (wb, h): query on the lane, 4 consecutive keys per quad; lives in VGPRs for the whole batch loop
     f32x4 bias[4][4];
     {
-        const float* bt = a.bias + ((size_t)wb * a.heads + h) * (PADT * PADT);
+        const float* dtile = a.dist ? a.dist + (size_t)(wb % a.n_dist) * (PADT * PADT) : nullptr;
+        const float* mtile = a.mask ? a.mask + (size_t)(wb % a.n_mask) * (PADT * PADT) : nullptr;
 #pragma unroll
         for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
             for (int tj = 0; tj < 4; ++tj)
-                bias[ti][tj] = *reinterpret_cast<const f32x4*>(bt + (16 * ti + c) * PADT + 16 * tj + 4 * g);
+                bias[ti][tj] = bias_quad<false>(dtile, mtile, tab_a, tab_b, 16 * ti + c, 16 * tj + 4 * g);
     }
 
     for (int r = 0; r < a.reps_per_chunk; ++r) {
         const size_t win = (size_t)(chunk * a.reps_per_chunk + r) * a.nb + wb;
         const size_t row0 = win * TOK;
-        Frag<DT> qf[4], kf[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const int row = 16 * t + c;
-            const bool ok = row < TOK;
-            const size_t off = (row0 + row) * (size_t)a.ld_qkv + h * HD + 8 * g;
-            qf[t] = scale_frag<DT>(load_frag<DT>(a.q, off, ok), a.scale);
-            kf[t] = load_frag<DT>(a.k, off, ok);
-            Frag<DT> vf = load_frag<DT>(a.v, off, ok);
-            lds_write_frag<DT, HD>(vimg, row, 8 * g, vf);    // rows >= 49 are written as zeros
+        for (int t = 0; t < 4; ++t) lds_write_frag<DT, HD>(vimg, 16 * t + c, 8 * g, cur.v[t]);   // rows >= 49: zeros
+        // S^T tiles: keys 16 tj + 4 g + e on the accumulator rows, query 16 ti + c on the lane
+        f32x4 s4[4][4];
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) {
+            const Frag<DT> qs = scale_frag<DT>(cur.q[ti], a.scale);
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj) s4[ti][tj] = mma32<DT>(cur.k[tj], qs, bias[ti][tj]);
         }
+        // the operand registers are free: request the next image now, its latency hides under softmax + PV
+        if (r + 1 < a.reps_per_chunk) load_tiles(r + 1, cur);
         // V^T operand fragments: [k-step s][d tile dt]
         Frag<DT> vt[2][2];
 #pragma unroll
@@ -270,45 +377,57 @@ __global__ __launch_bounds__(64 * WAVES) void attn_fwd_kernel(AttnArgs a) {
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) vt[s][dt] = lds_read_tr<DT, HD>(vimg, 32 * s + 4 * g, 16 * dt, c, g);
 
+        // softmax in phases over the 4 query tiles, so that the 4 independent cross-lane chains overlap
+        float m[4], l[4];
 #pragma unroll
         for (int ti = 0; ti < 4; ++ti) {
-            // S^T tile row: keys 16 tj + 4 g + r on the accumulator, query 16 ti + c on the lane
-            f32x4 s4[4];
-#pragma unroll
-            for (int tj = 0; tj < 4; ++tj) s4[tj] = mma32<DT>(kf[tj], qf[ti], bias[ti][tj]);
-            float m = -INFINITY;
+            float mm = -INFINITY;
 #pragma unroll
             for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) m = fmaxf(m, s4[tj][e]);
-            m = group_max(m);
-            const float mb = m * LOG2E;
-            float l = 0.f;
+                for (int e = 0; e < 4; ++e) mm = fmaxf(mm, s4[ti][tj][e]);
+            m[ti] = mm;
+        }
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) m[ti] = group_max(m[ti]);
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) {
+            const float mb = m[ti] * LOG2E;
+            float ll = 0.f;
 #pragma unroll
             for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float p = __builtin_amdgcn_exp2f(s4[tj][e] * LOG2E - mb);
-                    s4[tj][e] = p;
-                    l += p;
+                    const float p = __builtin_amdgcn_exp2f(s4[ti][tj][e] * LOG2E - mb);
+                    s4[ti][tj][e] = p;
+                    ll += p;
                 }
-            l = group_sum(l);
-            // O^T[d][i] = sum_j V^T[d][j] P^T[j][i]
-            f32x4 o[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+            l[ti] = ll;
+        }
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) l[ti] = group_sum(l[ti]);
+        // O^T[d][i] = sum_j V^T[d][j] P^T[j][i]
+        f32x4 o[4][2];
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) {
+            o[ti][0] = o[ti][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                Frag<DT> pf = pack_frag<DT>(s4[2 * s], s4[2 * s + 1]);
+                const Frag<DT> pf = pack_frag<DT>(s4[ti][2 * s], s4[ti][2 * s + 1]);
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt) o[dt] = mma32<DT>(vt[s][dt], pf, o[dt]);
+                for (int dt = 0; dt < 2; ++dt) o[ti][dt] = mma32<DT>(vt[s][dt], pf, o[ti][dt]);
             }
+        }
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti) {
             const int i = 16 * ti + c;
-            const float inv_l = 1.0f / l;
+            const float inv_l = 1.0f / l[ti];
             if (i < TOK) {
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt)
-                    store_quad<DT>(a.out, (row0 + i) * (size_t)a.ld_out + h * HD + 16 * dt + 4 * g, o[dt] * inv_l);
+                    store_quad<DT>(a.out, (row0 + i) * (size_t)a.ld_out + h * HD + 16 * dt + 4 * g, o[ti][dt] * inv_l);
             }
-            if (g == 0) a.lse[(win * a.heads + h) * PADT + i] = (i < TOK) ? m + logf(l) : INFINITY;
+            if (g == 0) a.lse[(win * a.heads + h) * PADT + i] = (i < TOK) ? m[ti] + logf(l[ti]) : INFINITY;
         }
     }
 }
@@ -320,7 +439,7 @@ template <int DT>
 struct BwdLds {
     static constexpr int ROW = LdsImg<DT, HD>::BYTES;      // Q, K, dO images [64][32]
     static constexpr int TT = LdsImg<DT, PADT>::BYTES;     // dS^T image [64 keys][64 queries]
-    static constexpr int BYTES = 3 * ROW + TT;
+    static constexpr int BYTES = 3 * ROW + TT + 2 * TABP * 4;   // + table columns (alpha, beta)
 };
 
 template <int DT, int WAVES>
@@ -338,30 +457,59 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_kernel(AttnArgs a) {
     char* kimg = qimg + L::ROW;
     char* doimg = kimg + L::ROW;
     char* timg = doimg + L::ROW;
-    const float* bt = a.bias + ((size_t)wb * a.heads + h) * (PADT * PADT);   // bias_ji: [key j][query i]
+    float* tab_a = reinterpret_cast<float*>(timg + L::TT);
+    float* tab_b = tab_a + TABP;
+    const float* dtile = a.dist ? a.dist + (size_t)(wb % a.n_dist) * (PADT * PADT) : nullptr;   // transposed: [j][i]
+    const float* mtile = a.mask ? a.mask + (size_t)(wb % a.n_mask) * (PADT * PADT) : nullptr;
 
-    f32x4 gsum[4][4];   // sum over the batch loop of dS: [ti][tj], rows i = 16 ti + 4 g + e, column j = 16 tj + c
+    auto load_tiles = [&](int r, Tiles4<DT>& t) {
+        const size_t row0 = ((size_t)(chunk * a.reps_per_chunk + r) * a.nb + wb) * TOK;
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const int row = 16 * tt + c;
+            const bool ok = row < TOK;
+            const size_t off = (row0 + row) * (size_t)a.ld_qkv + h * HD + 8 * g;
+            t.q[tt] = load_frag<DT>(a.q, off, ok);
+            t.k[tt] = load_frag<DT>(a.k, off, ok);
+            t.v[tt] = load_frag<DT>(a.v, off, ok);
+            t.d[tt] = load_frag<DT>(a.dout, (row0 + row) * (size_t)a.ld_out + h * HD + 8 * g, ok);
+        }
+    };
+
+    constexpr bool DUAL = (DT == PSWIN_BF16);
+    Tiles4<DT> cur, nxt;
+    load_tiles(0, cur);              // in flight while the bias is being built
+
+    load_tables(a, h, lane, tab_a, tab_b);
+    __builtin_amdgcn_wave_barrier();
+    // bias in the backward layout: rows i = 16 ti + 4 g + e on the registers, key j = 16 tj + c on the lane
+    f32x4 bias[4][4];
+#pragma unroll
+    for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj)
+            bias[ti][tj] = bias_quad<true>(dtile, mtile, tab_a, tab_b, 16 * ti + 4 * g, 16 * tj + c);
+
+    f32x4 gsum[4][4];   // sum over the batch loop of dS
 #pragma unroll
     for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj) gsum[ti][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // bf16: a second register set holds the next image's operands for a whole iteration (64 VGPRs).  f32 operands
+    // are twice as large, so the f32 (parity) path reuses the one set as soon as the MFMAs have consumed it.
     for (int r = 0; r < a.reps_per_chunk; ++r) {
         const size_t win = (size_t)(chunk * a.reps_per_chunk + r) * a.nb + wb;
         const size_t row0 = win * TOK;
-        Frag<DT> qf[4], kf[4], vf[4], dof[4];
+        if constexpr (DUAL) {
+            if (r + 1 < a.reps_per_chunk) load_tiles(r + 1, nxt);
+        }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int row = 16 * t + c;
-            const bool ok = row < TOK;
-            const size_t off = (row0 + row) * (size_t)a.ld_qkv + h * HD + 8 * g;
-            qf[t] = scale_frag<DT>(load_frag<DT>(a.q, off, ok), a.scale);
-            kf[t] = load_frag<DT>(a.k, off, ok);
-            vf[t] = load_frag<DT>(a.v, off, ok);
-            dof[t] = load_frag<DT>(a.dout, (row0 + row) * (size_t)a.ld_out + h * HD + 8 * g, ok);
-            lds_write_frag<DT, HD>(qimg, row, 8 * g, qf[t]);
-            lds_write_frag<DT, HD>(kimg, row, 8 * g, kf[t]);
-            lds_write_frag<DT, HD>(doimg, row, 8 * g, dof[t]);
+            cur.q[t] = scale_frag<DT>(cur.q[t], a.scale);
+            lds_write_frag<DT, HD>(qimg, 16 * t + c, 8 * g, cur.q[t]);
+            lds_write_frag<DT, HD>(kimg, 16 * t + c, 8 * g, cur.k[t]);
+            lds_write_frag<DT, HD>(doimg, 16 * t + c, 8 * g, cur.d[t]);
         }
         f32x4 dv[2][4], dk[2][4];   // [dt][tj]: rows d = 16 dt + 4 g + e, column key j = 16 tj + c
 #pragma unroll
@@ -383,12 +531,11 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_kernel(AttnArgs a) {
                 f32x4 delta = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int tj = 0; tj < 4; ++tj) {
-                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bt + (16 * tj + c) * PADT + 16 * ti + 4 * g);
-                    f32x4 sc = mma32<DT>(qf[ti], kf[tj], b4);                       // S[i][j] + bias
-                    f32x4 dp = mma32<DT>(dof[ti], vf[tj], f32x4{0.f, 0.f, 0.f, 0.f});   // dP[i][j]
+                    const f32x4 sc = mma32<DT>(cur.q[ti], cur.k[tj], bias[ti][tj]);                  // S[i][j] + bias
+                    const f32x4 dp = mma32<DT>(cur.d[ti], cur.v[tj], f32x4{0.f, 0.f, 0.f, 0.f});     // dP[i][j]
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float p = __builtin_amdgcn_exp2f((sc[e] - lse4[e]) * LOG2E);
+                        const float p = __builtin_amdgcn_exp2f((sc[e] - lse4[e]) * LOG2E);
                         p4[tt][tj][e] = p;
                         delta[e] += p * dp[e];
                     }
@@ -413,14 +560,17 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_kernel(AttnArgs a) {
             }
 #pragma unroll
             for (int tj = 0; tj < 4; ++tj) {
-                Frag<DT> pf = pack_frag<DT>(p4[0][tj], p4[1][tj]);
-                Frag<DT> dsf = pack_frag<DT>(ds4[0][tj], ds4[1][tj]);
+                const Frag<DT> pf = pack_frag<DT>(p4[0][tj], p4[1][tj]);
+                const Frag<DT> dsf = pack_frag<DT>(ds4[0][tj], ds4[1][tj]);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
                     dv[dt][tj] = mma32<DT>(dot[dt], pf, dv[dt][tj]);
                     dk[dt][tj] = mma32<DT>(qt[dt], dsf, dk[dt][tj]);
                 }
             }
+        }
+        if constexpr (!DUAL) {
+            if (r + 1 < a.reps_per_chunk) load_tiles(r + 1, cur);
         }
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj) {
@@ -447,7 +597,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_kernel(AttnArgs a) {
             for (int dt = 0; dt < 2; ++dt) kt[dt] = lds_read_tr<DT, HD>(kimg, 32 * s + 4 * g, 16 * dt, c, g);
 #pragma unroll
             for (int ti = 0; ti < 4; ++ti) {
-                Frag<DT> tf = lds_read_tr<DT, PADT>(timg, 32 * s + 4 * g, 16 * ti, c, g);
+                const Frag<DT> tf = lds_read_tr<DT, PADT>(timg, 32 * s + 4 * g, 16 * ti, c, g);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) dq[dt][ti] = mma32<DT>(kt[dt], tf, dq[dt][ti]);
             }
@@ -462,9 +612,14 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_kernel(AttnArgs a) {
                                    dq[dt][ti] * a.scale);
             }
         }
+        if constexpr (DUAL) {
+            if (r + 1 < a.reps_per_chunk) cur = nxt;
+        }
     }
-    if (a.dbias) {
-        float* gt = a.dbias + (((size_t)chunk * a.nb + wb) * a.heads + h) * (PADT * PADT);
+    // sum over this work item's images of dS, as a transposed [key j][query i] tile; binned into the tables by
+    // dtab_partial_kernel (LDS float atomics in here cost ~100 cycles per wave-instruction: measured 1.6x the kernel)
+    if (a.dtab) {
+        float* gt = a.dtab + (size_t)item * (PADT * PADT);
 #pragma unroll
         for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
@@ -474,76 +629,51 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_kernel(AttnArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// bias tiles and their adjoint
+// helpers around the main kernels
 // ---------------------------------------------------------------------------------------------
-__device__ inline int rel_index(int i, int j) {
-    return (i / PSWIN_WS - j / PSWIN_WS + PSWIN_WS - 1) * (2 * PSWIN_WS - 1) + (i % PSWIN_WS - j % PSWIN_WS + PSWIN_WS - 1);
-}
-
-__global__ void bias_build_kernel(const float* __restrict__ dist, int n_dist, const float* __restrict__ alpha,
-                                  const float* __restrict__ beta, const float* __restrict__ mask, int n_mask,
-                                  int heads, float* __restrict__ bias_ij, float* __restrict__ bias_ji) {
-    const int wb = blockIdx.x;
+// [n][49][49] -> [n][64][64], optionally transposed, zero padded: the tile layout the attention kernels read
+__global__ void pad_tiles_kernel(const float* __restrict__ src, int n, int transpose, float* __restrict__ dst) {
+    const size_t t = blockIdx.x;
     for (int e = threadIdx.x; e < PADT * PADT; e += blockDim.x) {
-        const int i = e / PADT, j = e - i * PADT;
-        const bool real = i < TOK && j < TOK;
-        float d = 0.f, mk = 0.f;
-        int idx = 0;
-        if (real) {
-            idx = rel_index(i, j);
-            if (dist) d = dist[((size_t)(wb % n_dist) * TOK + i) * TOK + j];
-            if (mask) mk = mask[((size_t)(wb % n_mask) * TOK + i) * TOK + j];
-        }
-        for (int h = 0; h < heads; ++h) {
-            float val;
-            if (real) {
-                // same rounding sequence as the reference: (d * alpha + beta) [+ mask]   (HOT:255-256, 294, 301)
-                val = beta[idx * heads + h];
-                if (dist) val = __fadd_rn(__fmul_rn(d, alpha[idx * heads + h]), val);
-                if (mask) val = __fadd_rn(val, mk);
-            } else {
-                val = (j >= TOK) ? -INFINITY : 0.f;
-            }
-            const size_t tile = ((size_t)wb * heads + h) * (PADT * PADT);
-            bias_ij[tile + i * PADT + j] = val;
-            if (bias_ji) bias_ji[tile + j * PADT + i] = val;
-        }
+        const int r = e / PADT, col = e - r * PADT;
+        float v = 0.f;
+        if (r < TOK && col < TOK) v = transpose ? src[(t * TOK + col) * TOK + r] : src[(t * TOK + r) * TOK + col];
+        dst[t * PADT * PADT + e] = v;
     }
 }
 
-constexpr int NBINS = (2 * PSWIN_WS - 1) * (2 * PSWIN_WS - 1);   // 169
-constexpr int BIAS_BWD_BLOCKS = 128;
-constexpr int BIAS_BWD_THREADS = 256;
-constexpr int BIAS_BWD_EPT = (TOK * TOK + BIAS_BWD_THREADS - 1) / BIAS_BWD_THREADS;   // 10 (i, j) pairs per thread
+constexpr int DTAB_BLOCKS = 128;
+constexpr int DTAB_THREADS = 256;
+constexpr int DTAB_EPT = (TOK * TOK + DTAB_THREADS - 1) / DTAB_THREADS;   // 10 (i, j) pairs per thread
 
-// Stage 1: per block and head, sum over a strided subset of the tiles of g and g * dist for every (i, j) pair.
-// No atomics: a thread owns the same 10 pairs for every tile, so the sums stay in registers.
-// partial[block][h][2][49*49]
-__global__ __launch_bounds__(BIAS_BWD_THREADS) void bias_bwd_partial_kernel(
-    const float* __restrict__ dbias_ji, int n_tiles, int nb, const float* __restrict__ dist, int n_dist, int heads,
-    float* __restrict__ partial) {
+// Stage 1: per block and head, sum over a strided subset of the G tiles of g and g * d for every (i, j) pair.  A
+// thread owns the same 10 pairs for every tile, so the sums stay in registers (no atomics).
+// g tiles: [n_tiles][heads][64 j][64 i]; dist_t tiles: [n_dist][64 j][64 i]; partial: [block][heads][2][49*49]
+__global__ __launch_bounds__(DTAB_THREADS) void dtab_partial_kernel(const float* __restrict__ g, int n_tiles, int nb,
+                                                                    const float* __restrict__ dist_t, int n_dist,
+                                                                    int heads, float* __restrict__ partial) {
     const int h = blockIdx.y;
-    float sb[BIAS_BWD_EPT], sa[BIAS_BWD_EPT];
+    float sb[DTAB_EPT], sa[DTAB_EPT];
 #pragma unroll
-    for (int k = 0; k < BIAS_BWD_EPT; ++k) sb[k] = sa[k] = 0.f;
+    for (int k = 0; k < DTAB_EPT; ++k) sb[k] = sa[k] = 0.f;
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
-        const float* gt = dbias_ji + ((size_t)tile * heads + h) * (PADT * PADT);
-        const float* dt = dist ? dist + (size_t)((tile % nb) % n_dist) * TOK * TOK : nullptr;
+        const float* gt = g + ((size_t)tile * heads + h) * (PADT * PADT);
+        const float* dt = dist_t ? dist_t + (size_t)((tile % nb) % n_dist) * (PADT * PADT) : nullptr;
 #pragma unroll
-        for (int k = 0; k < BIAS_BWD_EPT; ++k) {
-            const int e = threadIdx.x + k * BIAS_BWD_THREADS;      // e = j * 49 + i: i contiguous in the ji tile
+        for (int k = 0; k < DTAB_EPT; ++k) {
+            const int e = threadIdx.x + k * DTAB_THREADS;      // e = j * 49 + i: i contiguous in the tiles
             if (e < TOK * TOK) {
                 const int j = e / TOK, i = e - j * TOK;
                 const float gval = gt[j * PADT + i];
                 sb[k] += gval;
-                if (dt) sa[k] += gval * dt[i * TOK + j];
+                if (dt) sa[k] += gval * dt[j * PADT + i];
             }
         }
     }
     float* out = partial + ((size_t)blockIdx.x * heads + h) * 2 * TOK * TOK;
 #pragma unroll
-    for (int k = 0; k < BIAS_BWD_EPT; ++k) {
-        const int e = threadIdx.x + k * BIAS_BWD_THREADS;
+    for (int k = 0; k < DTAB_EPT; ++k) {
+        const int e = threadIdx.x + k * DTAB_THREADS;
         if (e < TOK * TOK) {
             out[e] = sb[k];
             out[TOK * TOK + e] = sa[k];
@@ -551,10 +681,10 @@ __global__ __launch_bounds__(BIAS_BWD_THREADS) void bias_bwd_partial_kernel(
     }
 }
 
-// Stage 2 (after the column sum over blocks): one thread per (table entry, head) adds the <= 49 pairs of its entry.
+// Stage 2 (after the fixed-order column sum over blocks): one thread per (table entry, head) adds its <= 49 pairs.
 // summed: [heads][2][49*49]
-__global__ void bias_bwd_final_kernel(const float* __restrict__ summed, int heads, bool has_dist,
-                                      float* __restrict__ dalpha, float* __restrict__ dbeta) {
+__global__ void dtab_final_kernel(const float* __restrict__ summed, int heads, bool has_dist,
+                                  float* __restrict__ dalpha, float* __restrict__ dbeta) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;   // over 169 * heads
     if (t >= NBINS * heads) return;
     const int idx = t / heads, h = t - idx * heads;
@@ -576,9 +706,12 @@ __global__ void bias_bwd_final_kernel(const float* __restrict__ summed, int head
     if (dalpha) dalpha[t] = sa;
 }
 
-inline int pick_chunks(int reps, int nb, int heads) {
-    // enough independent waves to fill 256 CUs x 8 waves, while keeping the batch loop (bias reuse) long
-    const long long target = 4096;
+// Work items per bias window.  More chunks = more independent waves but the per-item setup (bias build, and the dS-sum
+// tile in the backward pass) is repeated and the batch loop that amortises it gets shorter.  Targets fitted to the
+// PanoSwin-T stage shapes on MI355X (tools/bench_attn.py): forward (2 waves/SIMD) ~1100 items, backward
+// (1 wave/SIMD, heavier items) ~600 items.
+inline int pick_chunks(int reps, int nb, int heads, bool backward) {
+    const long long target = backward ? 600 : 1100;
     int best = reps;
     for (int ch = 1; ch <= reps; ++ch) {
         if (reps % ch) continue;
@@ -591,71 +724,85 @@ inline int pick_chunks(int reps, int nb, int heads) {
 }
 
 inline int check_attn_common(const void* q, const void* k, const void* v, int ld_qkv, int n_windows, int nb,
-                             int heads, int dtype) {
-    PSWIN_CHECK_ARG(q && k && v);
+                             int heads, int dtype, const float* dist, int n_dist, const float* alpha,
+                             const float* beta, const float* mask, int n_mask) {
+    PSWIN_CHECK_ARG(q && k && v && beta);
     PSWIN_CHECK_ARG(valid_dtype(dtype));
     PSWIN_CHECK_ARG(n_windows > 0 && nb > 0 && heads > 0 && n_windows % nb == 0);
     PSWIN_CHECK_ARG(ld_qkv >= heads * HD && ld_qkv % 8 == 0);
-    PSWIN_CHECK_ARG(aligned16(q) && aligned16(k) && aligned16(v));
+    PSWIN_CHECK_ARG(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(dist) && aligned16(mask));
     PSWIN_CHECK_ARG((long long)n_windows * TOK * ld_qkv < (1ll << 40));
+    PSWIN_CHECK_ARG(!dist || (alpha && n_dist > 0 && nb % n_dist == 0));
+    PSWIN_CHECK_ARG(!mask || (n_mask > 0 && nb % n_mask == 0));
     return PSWIN_OK;
 }
 
 }  // namespace
 
-extern "C" int pswin_attn_bias_build(const float* dist, int n_dist, const float* alpha, const float* beta,
-                                     const float* mask, int n_mask, int n_bias_windows, int heads, float* bias_ij,
-                                     float* bias_ji, void* stream) {
-    PSWIN_CHECK_ARG(beta && bias_ij && n_bias_windows > 0 && heads > 0);
-    PSWIN_CHECK_ARG(!dist || (alpha && n_dist > 0 && n_bias_windows % n_dist == 0));
-    PSWIN_CHECK_ARG(!mask || (n_mask > 0 && n_bias_windows % n_mask == 0));
-    hipLaunchKernelGGL(bias_build_kernel, dim3(n_bias_windows), dim3(256), 0, (hipStream_t)stream, dist,
-                       dist ? n_dist : 1, alpha, beta, mask, mask ? n_mask : 1, heads, bias_ij, bias_ji);
+extern "C" int pswin_attn_pad_tiles(const float* src, int n, int transpose, float* dst, void* stream) {
+    PSWIN_CHECK_ARG(src && dst && n > 0 && aligned16(dst));
+    hipLaunchKernelGGL(pad_tiles_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, src, n, transpose, dst);
     PSWIN_LAUNCH_RET();
 }
 
-extern "C" int pswin_attn_fwd(const void* q, const void* k, const void* v, int ld_qkv, const float* bias_ij,
-                              void* out, int ld_out, float* lse, int n_windows, int n_bias_windows, int heads,
+extern "C" int pswin_attn_fwd(const void* q, const void* k, const void* v, int ld_qkv, const float* dist, int n_dist,
+                              const float* alpha, const float* beta, const float* mask, int n_mask, void* out,
+                              int ld_out, float* lse, int n_chunks, int n_windows, int n_bias_windows, int heads,
                               float scale, int dtype, void* stream) {
-    int rc = check_attn_common(q, k, v, ld_qkv, n_windows, n_bias_windows, heads, dtype);
+    int rc = check_attn_common(q, k, v, ld_qkv, n_windows, n_bias_windows, heads, dtype, dist, n_dist, alpha, beta,
+                               mask, n_mask);
     if (rc) return rc;
-    PSWIN_CHECK_ARG(bias_ij && out && lse && aligned16(out) && aligned16(bias_ij));
+    PSWIN_CHECK_ARG(out && lse && aligned16(out));
     PSWIN_CHECK_ARG(ld_out >= heads * HD && ld_out % 8 == 0);
     const int reps = n_windows / n_bias_windows;
-    const int chunks = pick_chunks(reps, n_bias_windows, heads);
+    PSWIN_CHECK_ARG(n_chunks >= 0 && n_chunks <= reps && (n_chunks == 0 || reps % n_chunks == 0));
+    const int chunks = n_chunks ? n_chunks : pick_chunks(reps, n_bias_windows, heads, false);
     AttnArgs a = {};
-    a.q = q; a.k = k; a.v = v; a.bias = bias_ij; a.out = out; a.lse = lse;
+    a.q = q; a.k = k; a.v = v; a.dist = dist; a.mask = mask; a.alpha = alpha; a.beta = beta;
+    a.n_dist = dist ? n_dist : 1; a.n_mask = mask ? n_mask : 1;
+    a.out = out; a.lse = lse;
     a.ld_qkv = ld_qkv; a.ld_out = ld_out;
     a.nb = n_bias_windows; a.heads = heads; a.reps_per_chunk = reps / chunks;
     a.n_items = chunks * n_bias_windows * heads;
     a.scale = scale;
-    if (dtype == PSWIN_BF16) {
-        constexpr int W = 4;
+    constexpr int W = 4;
+    if (dtype == PSWIN_BF16)
         hipLaunchKernelGGL((attn_fwd_kernel<PSWIN_BF16, W>), dim3((a.n_items + W - 1) / W), dim3(64 * W), 0,
                            (hipStream_t)stream, a);
-    } else {
-        constexpr int W = 4;
+    else
         hipLaunchKernelGGL((attn_fwd_kernel<PSWIN_F32, W>), dim3((a.n_items + W - 1) / W), dim3(64 * W), 0,
                            (hipStream_t)stream, a);
-    }
     PSWIN_LAUNCH_RET();
 }
 
-extern "C" int pswin_attn_bwd(const void* q, const void* k, const void* v, int ld_qkv, const float* bias_ji,
+extern "C" int pswin_attn_suggest_chunks(int n_windows, int n_bias_windows, int heads, int backward) {
+    if (n_windows <= 0 || n_bias_windows <= 0 || heads <= 0 || n_windows % n_bias_windows) return PSWIN_ERR_ARG;
+    return pick_chunks(n_windows / n_bias_windows, n_bias_windows, heads, backward != 0);
+}
+
+extern "C" int pswin_attn_table_grads_workspace(int heads) {
+    return heads > 0 ? (DTAB_BLOCKS + 1) * heads * 2 * TOK * TOK : PSWIN_ERR_ARG;   // block partials + their sum
+}
+
+extern "C" int pswin_attn_bwd(const void* q, const void* k, const void* v, int ld_qkv, const float* dist_t, int n_dist,
+                              const float* alpha, const float* beta, const float* mask_t, int n_mask,
                               const void* dout, int ld_out, const float* lse, void* dq, void* dk, void* dv,
-                              int ld_dqkv, float* dbias_ji, int n_chunks, int n_windows, int n_bias_windows,
+                              int ld_dqkv, float* dscore_sum, int n_chunks, int n_windows, int n_bias_windows,
                               int heads, float scale, int dtype, void* stream) {
-    int rc = check_attn_common(q, k, v, ld_qkv, n_windows, n_bias_windows, heads, dtype);
+    int rc = check_attn_common(q, k, v, ld_qkv, n_windows, n_bias_windows, heads, dtype, dist_t, n_dist, alpha, beta,
+                               mask_t, n_mask);
     if (rc) return rc;
-    PSWIN_CHECK_ARG(bias_ji && dout && lse && dq && dk && dv);
-    PSWIN_CHECK_ARG(aligned16(dout) && aligned16(dq) && aligned16(dk) && aligned16(dv) && aligned16(bias_ji) &&
-                    aligned16(lse) && aligned16(dbias_ji));
+    PSWIN_CHECK_ARG(dout && lse && dq && dk && dv);
+    PSWIN_CHECK_ARG(aligned16(dout) && aligned16(dq) && aligned16(dk) && aligned16(dv) && aligned16(lse));
     PSWIN_CHECK_ARG(ld_out >= heads * HD && ld_out % 8 == 0 && ld_dqkv >= heads * HD && ld_dqkv % 8 == 0);
     const int reps = n_windows / n_bias_windows;
     PSWIN_CHECK_ARG(n_chunks >= 1 && n_chunks <= reps && reps % n_chunks == 0);
+    PSWIN_CHECK_ARG(aligned16(dscore_sum));
     AttnArgs a = {};
-    a.q = q; a.k = k; a.v = v; a.bias = bias_ji; a.dout = dout; a.lse = const_cast<float*>(lse);
-    a.dq = dq; a.dk = dk; a.dv = dv; a.dbias = dbias_ji;
+    a.q = q; a.k = k; a.v = v; a.dist = dist_t; a.mask = mask_t; a.alpha = alpha; a.beta = beta;
+    a.n_dist = dist_t ? n_dist : 1; a.n_mask = mask_t ? n_mask : 1;
+    a.dout = dout; a.lse = const_cast<float*>(lse);
+    a.dq = dq; a.dk = dk; a.dv = dv; a.dtab = dscore_sum;
     a.ld_qkv = ld_qkv; a.ld_out = ld_out; a.ld_dqkv = ld_dqkv;
     a.nb = n_bias_windows; a.heads = heads; a.reps_per_chunk = reps / n_chunks;
     a.n_items = n_chunks * n_bias_windows * heads;
@@ -672,28 +819,21 @@ extern "C" int pswin_attn_bwd(const void* q, const void* k, const void* v, int l
     PSWIN_LAUNCH_RET();
 }
 
-extern "C" int pswin_attn_suggest_chunks(int n_windows, int n_bias_windows, int heads) {
-    if (n_windows <= 0 || n_bias_windows <= 0 || heads <= 0 || n_windows % n_bias_windows) return PSWIN_ERR_ARG;
-    return pick_chunks(n_windows / n_bias_windows, n_bias_windows, heads);
-}
-
-extern "C" int pswin_attn_bias_bwd_workspace(int heads) {
-    return heads > 0 ? (BIAS_BWD_BLOCKS + 1) * heads * 2 * TOK * TOK : PSWIN_ERR_ARG;
-}
-
-extern "C" int pswin_attn_bias_bwd(const float* dbias_ji, int n_tiles, int n_bias_windows, const float* dist,
-                                   int n_dist, int heads, float* dalpha, float* dbeta, float* workspace,
-                                   void* stream) {
-    PSWIN_CHECK_ARG(dbias_ji && dbeta && workspace && n_tiles > 0 && n_bias_windows > 0 && heads > 0);
+extern "C" int pswin_attn_table_grads(const float* dscore_sum, int n_tiles, int n_bias_windows, const float* dist_t,
+                                      int n_dist, int heads, float* dalpha, float* dbeta, float* workspace,
+                                      void* stream) {
+    PSWIN_CHECK_ARG(dscore_sum && dbeta && workspace && n_tiles > 0 && n_bias_windows > 0 && heads > 0);
     PSWIN_CHECK_ARG(n_tiles % n_bias_windows == 0);
-    PSWIN_CHECK_ARG(!dist || (n_dist > 0 && n_bias_windows % n_dist == 0));
-    const int blocks = n_tiles < BIAS_BWD_BLOCKS ? n_tiles : BIAS_BWD_BLOCKS;
-    hipLaunchKernelGGL(bias_bwd_partial_kernel, dim3(blocks, heads), dim3(BIAS_BWD_THREADS), 0, (hipStream_t)stream,
-                       dbias_ji, n_tiles, n_bias_windows, dist, dist ? n_dist : 1, heads, workspace);
+    PSWIN_CHECK_ARG(!dist_t || (dalpha && n_dist > 0 && n_bias_windows % n_dist == 0));
+    // tiles are ordered (chunk, wb, h): tile x of head h belongs to bias window x % n_bias_windows
+    const int blocks = n_tiles < DTAB_BLOCKS ? n_tiles : DTAB_BLOCKS;
     const int ncol = heads * 2 * TOK * TOK;
-    float* summed = workspace + (size_t)BIAS_BWD_BLOCKS * ncol;
-    launch_colsum(workspace, blocks, ncol, summed, (hipStream_t)stream);
-    hipLaunchKernelGGL(bias_bwd_final_kernel, dim3((NBINS * heads + 63) / 64), dim3(64), 0, (hipStream_t)stream,
-                       summed, heads, dist != nullptr, dist ? dalpha : nullptr, dbeta);
+    float* partial = workspace;
+    float* summed = partial + (size_t)DTAB_BLOCKS * ncol;
+    hipLaunchKernelGGL(dtab_partial_kernel, dim3(blocks, heads), dim3(DTAB_THREADS), 0, (hipStream_t)stream, dscore_sum,
+                       n_tiles, n_bias_windows, dist_t, dist_t ? n_dist : 1, heads, partial);
+    launch_colsum(partial, blocks, ncol, summed, (hipStream_t)stream);
+    hipLaunchKernelGGL(dtab_final_kernel, dim3((NBINS * heads + 63) / 64), dim3(64), 0, (hipStream_t)stream, summed,
+                       heads, dist_t != nullptr, dist_t ? dalpha : nullptr, dbeta);
     PSWIN_LAUNCH_RET();
 }

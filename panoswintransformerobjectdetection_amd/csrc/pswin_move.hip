@@ -259,3 +259,92 @@ extern "C" int pswin_interp_rows_adjoint(const float* dout, const int32_t* idx, 
                        S, P, g.vpr);
     PSWIN_LAUNCH_RET();
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// Column sums of a row-major [M, N] matrix (bias gradients: db[n] = sum_m dY[m][n]; split-K partial sums).
+// Stage 1: every block streams a strided subset of the rows with 16-byte loads and keeps 8 (bf16) / 4 (f32) fp32
+// column sums per thread; the row lanes of a block are combined through LDS.  Stage 2: colsum_kernel over blocks.
+// ------------------------------------------------------------------------------------------------------------
+namespace {
+
+template <int DT>
+__global__ __launch_bounds__(256) void rowsum_partial_kernel(const void* __restrict__ x, long long M, int N,
+                                                             int vpr, int vprb, float* __restrict__ part) {
+    constexpr int VE = (DT == PSWIN_BF16) ? 8 : 4;        // elements per 16-byte vector
+    __shared__ float red[256 * VE];
+    const int rpi = 256 / vprb;                           // rows per iteration of this block
+    const int cl = threadIdx.x % vprb, rl = threadIdx.x / vprb;
+    const int cg = blockIdx.y * vprb + cl;                // 16-byte column group
+    float acc[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) acc[e] = 0.f;
+    if (rl < rpi && cg < vpr) {
+        for (long long r = (long long)blockIdx.x * rpi + rl; r < M; r += (long long)gridDim.x * rpi) {
+            if constexpr (DT == PSWIN_BF16) {
+                const u32x4 raw = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(x) +
+                                                                  (size_t)r * N + (size_t)cg * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[2 * e] += __builtin_bit_cast(float, raw[e] << 16);
+                    acc[2 * e + 1] += __builtin_bit_cast(float, raw[e] & 0xffff0000u);
+                }
+            } else {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(x) + (size_t)r * N +
+                                                                (size_t)cg * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] += v[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < VE; ++e) red[threadIdx.x * VE + e] = acc[e];
+    __syncthreads();
+    if (rl == 0 && cg < vpr) {
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+            float s = 0.f;
+            for (int q = 0; q < rpi; ++q) s += red[(q * vprb + cl) * VE + e];
+            part[(size_t)blockIdx.x * N + (size_t)cg * VE + e] = s;
+        }
+    }
+}
+
+constexpr int ROWSUM_MAX_BLOCKS = 512;
+
+inline int rowsum_blocks(long long M, int N, int dtype) {
+    const int ve = dtype == PSWIN_BF16 ? 8 : 4;
+    const int vpr = N / ve;
+    const int vprb = vpr < 256 ? vpr : 256;
+    const int rpi = 256 / vprb;
+    const int ychunks = (vpr + vprb - 1) / vprb;
+    long long nb = (M + (long long)rpi * 8 - 1) / ((long long)rpi * 8);        // >= 8 rows per row lane
+    const int cap = ROWSUM_MAX_BLOCKS / ychunks > 0 ? ROWSUM_MAX_BLOCKS / ychunks : 1;
+    if (nb > cap) nb = cap;
+    if (nb < 1) nb = 1;
+    return (int)nb;
+}
+
+}  // namespace
+
+extern "C" int pswin_colsum_workspace(long long M, int N, int dtype) {
+    if (M <= 0 || N <= 0 || !valid_dtype(dtype) || N % 8) return PSWIN_ERR_ARG;
+    return rowsum_blocks(M, N, dtype) * N;
+}
+
+extern "C" int pswin_colsum(const void* x, int dtype, long long M, int N, float* out, float* workspace, void* stream) {
+    PSWIN_CHECK_ARG(x && out && workspace && M > 0 && N > 0 && valid_dtype(dtype));
+    PSWIN_CHECK_ARG(N % 8 == 0 && aligned16(x));
+    const int ve = dtype == PSWIN_BF16 ? 8 : 4;
+    const int vpr = N / ve;
+    const int vprb = vpr < 256 ? vpr : 256;
+    const int ychunks = (vpr + vprb - 1) / vprb;
+    const int blocks = rowsum_blocks(M, N, dtype);
+    if (dtype == PSWIN_BF16)
+        hipLaunchKernelGGL(rowsum_partial_kernel<PSWIN_BF16>, dim3(blocks, ychunks), dim3(256), 0, (hipStream_t)stream,
+                           x, M, N, vpr, vprb, workspace);
+    else
+        hipLaunchKernelGGL(rowsum_partial_kernel<PSWIN_F32>, dim3(blocks, ychunks), dim3(256), 0, (hipStream_t)stream,
+                           x, M, N, vpr, vprb, workspace);
+    launch_colsum(workspace, blocks, N, out, (hipStream_t)stream);
+    PSWIN_LAUNCH_RET();
+}

@@ -36,7 +36,12 @@ def init_distributed(backend=None):
 
 
 class GradReducer:
-    def __init__(self, module, bucket_mb=32.0, process_group=None):
+    def __init__(self, module, bucket_mb=32.0, process_group=None, pack=False):
+        """pack=False: ``param.grad`` are views of the flat buffer and autograd accumulates into them (one small add
+        kernel per parameter).  pack=True: gradients are produced as free tensors (``param.grad = None`` before
+        backward) and gathered into the flat buffer by ONE multi-tensor copy in finish() -- fewer, larger launches;
+        meant for the hipGraph path where collectives run after backward anyway."""
+        self.pack = pack
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.params = [p for p in module.parameters() if p.requires_grad]
@@ -54,8 +59,10 @@ class GradReducer:
         limit = int(bucket_mb * 1024 * 1024 / 4)
         start = 0
         count = 0
+        self._order, self._views = order, []
         for i, p in enumerate(order):
-            p.grad = self.flat[offsets[i]:offsets[i] + p.numel()].view_as(p)
+            self._views.append(self.flat[offsets[i]:offsets[i] + p.numel()].view_as(p))
+            p.grad = None if pack else self._views[-1]
             self._bucket_of[p] = len(self.buckets)
             count += 1
             end = offsets[i + 1] if i + 1 < len(order) else total
@@ -67,11 +74,28 @@ class GradReducer:
         self._handles = []
         self.overlap = True          # launch buckets from backward hooks; set False to reduce everything in finish()
         self._use_avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
-        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params] if self.world > 1 else []
+        self.overlap = not pack
+        self._hooks = ([p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
+                       if self.world > 1 and not pack else [])
 
     # -- per step -----------------------------------------------------------------------------------------------
     def zero_grad(self):
-        self.flat.zero_()
+        if self.pack:
+            for p in self._order:
+                p.grad = None
+        else:
+            self.flat.zero_()
+
+    def pack_grads(self):
+        """pack mode: gather the freshly produced gradients into the flat buffer and re-point ``param.grad`` at it."""
+        have = [(v, p.grad) for v, p in zip(self._views, self._order) if p.grad is not None]
+        for v, p in zip(self._views, self._order):
+            if p.grad is None:
+                v.zero_()                                         # parameter unused this step: contributes zeros
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        for v, p in zip(self._views, self._order):
+            p.grad = v
 
     def _launch(self, b):
         if self._launched[b]:
@@ -93,7 +117,8 @@ class GradReducer:
             self._launch(b)
 
     def finish(self):
-        """Call after backward: launches buckets whose parameters got no gradient, waits for all of them."""
+        """Call after backward (and after pack_grads() in pack mode): launches the buckets not launched from hooks,
+        waits for all of them."""
         if self.world > 1:
             for b in range(len(self.buckets)):
                 self._launch(b)

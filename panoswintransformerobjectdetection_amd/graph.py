@@ -11,17 +11,21 @@ import torch
 
 
 class GraphedCallable:
-    def __init__(self, fn, warmup=3):
+    def __init__(self, fn, warmup=3, stream=None):
+        """Warm `fn` up and capture it ON THE SAME side stream: autograd's AccumulateGrad nodes remember the stream
+        they were created on, and a capture on a different stream would put them on a fork of the graph that is not
+        joined before the consumers of the gradients (observed: garbage gradients from the second replay on)."""
         self.fn = fn
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):                      # warm up off the default stream, as capture requires
+        self.stream = stream or torch.cuda.Stream()
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
             for _ in range(warmup):
-                fn()
-        torch.cuda.current_stream().wait_stream(side)
+                out = fn()
+            del out
+        torch.cuda.current_stream().wait_stream(self.stream)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, stream=self.stream):
             self.out = fn()
 
     def __call__(self):

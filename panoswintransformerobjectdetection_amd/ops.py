@@ -253,6 +253,16 @@ def layer_norm_patch_merge(x, gamma, beta, eps, H, W, out_dtype=None):
     return _LayerNormPatchMerge.apply(x, gamma, beta, eps, H, W, out_dtype or x.dtype)
 
 
+def colsum(x2d):
+    """fp32 column sums of a [M, N] matrix (N % 8 == 0): bias gradients and split-K partial reductions."""
+    x2d = x2d.contiguous()
+    M, N = x2d.shape
+    out = torch.empty(N, dtype=torch.float32, device=x2d.device)
+    ws = torch.empty(_lib.load().pswin_colsum_workspace(M, N, dtype_code(x2d)), dtype=torch.float32, device=x2d.device)
+    call("pswin_colsum", x2d, ptr(x2d), dtype_code(x2d), M, N, ptr(out), ptr(ws))
+    return out
+
+
 class _InterpRows(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, idx, wgt):
@@ -283,19 +293,43 @@ def interp_rows(x, idx, wgt):
 # ------------------------------------------------------------------------------------------------
 # window attention
 # ------------------------------------------------------------------------------------------------
-def build_bias(dist, alpha, beta, mask, n_bias_windows, heads, need_ji):
-    dev = beta.device
-    bias_ij = torch.empty(n_bias_windows, heads, WPAD, WPAD, dtype=torch.float32, device=dev)
-    bias_ji = torch.empty_like(bias_ij) if need_ji else None
-    call("pswin_attn_bias_build", beta, ptr(dist), 0 if dist is None else dist.shape[0], ptr(alpha), ptr(beta),
-         ptr(mask), 0 if mask is None else mask.shape[0], n_bias_windows, heads, ptr(bias_ij), ptr(bias_ji))
-    return bias_ij, bias_ji
+class Tiles:
+    """A [n, 49, 49] fp32 table as zero-padded 64 x 64 tiles: `fwd` holds tile[i][j], `bwd` the transposed tile[j][i]
+    (the same buffer when the table is symmetric, e.g. self-attention distances and the shifted-window mask)."""
+
+    def __init__(self, table, symmetric=False):
+        table = table.contiguous().float()
+        assert table.dim() == 3 and table.shape[1:] == (WTOK, WTOK)
+        self.n = table.shape[0]
+        self.table = table
+        self.fwd = torch.empty(self.n, WPAD, WPAD, dtype=torch.float32, device=table.device)
+        call("pswin_attn_pad_tiles", table, ptr(table), self.n, 0, ptr(self.fwd))
+        if symmetric:
+            self.bwd = self.fwd
+        else:
+            self.bwd = torch.empty_like(self.fwd)
+            call("pswin_attn_pad_tiles", table, ptr(table), self.n, 1, ptr(self.bwd))
 
 
-def _rows_view(t, C):
-    """(tensor, element pointer, row stride) of a [rows, C] view whose last dim is contiguous."""
-    assert t.dim() == 2 and t.shape[1] == C and t.stride(1) == 1, "q/k/v must be [rows, C] with unit inner stride"
-    return t.stride(0)
+def window_dist_tiles(H, W, shift, device):
+    """Tiles of window_dist (symmetric: haversine of a window with itself)."""
+    key = ("dist_tiles", H, W, shift, _dev_key(device))
+    if key not in _CACHE:
+        _CACHE[key] = Tiles(window_dist(H, W, shift, device), symmetric=True)
+    return _CACHE[key]
+
+
+def planar_mask_tiles(H, W, shift, device):
+    key = ("mask_tiles", H, W, shift, _dev_key(device))
+    if key not in _CACHE:
+        _CACHE[key] = Tiles(planar_mask(H, W, shift, device), symmetric=True)
+    return _CACHE[key]
+
+
+def _as_tiles(t):
+    if t is None or isinstance(t, Tiles):
+        return t
+    return Tiles(t)
 
 
 class _WindowAttention(torch.autograd.Function):
@@ -303,7 +337,8 @@ class _WindowAttention(torch.autograd.Function):
     (k = v = None) or three separate [rows, C] tensors."""
 
     @staticmethod
-    def forward(ctx, q_or_qkv, k, v, alpha, beta, dist, mask, heads, scale, n_bias_windows):
+    def forward(ctx, q_or_qkv, k, v, alpha, beta, dist, mask, heads, scale, n_bias_windows, chunks):
+        import ctypes
         fused = k is None
         x = q_or_qkv.contiguous()
         C = heads * _lib.HEAD_DIM
@@ -321,25 +356,26 @@ class _WindowAttention(torch.autograd.Function):
             assert x.dtype == k.dtype == v.dtype
             ld = C
             qp, kp, vp = x.data_ptr(), k.data_ptr(), v.data_ptr()
-        need_grad = any(ctx.needs_input_grad[:5])
-        bias_ij, bias_ji = build_bias(dist, alpha if dist is not None else None, beta, mask, n_bias_windows, heads,
-                                      need_grad)
+        alpha = alpha.contiguous() if dist is not None else None
+        beta = beta.contiguous()
         out = torch.empty(rows, C, dtype=x.dtype, device=x.device)
         lse = torch.empty(n, heads, WPAD, dtype=torch.float32, device=x.device)
-        import ctypes
-        call("pswin_attn_fwd", x, ctypes.c_void_p(qp), ctypes.c_void_p(kp), ctypes.c_void_p(vp), ld, ptr(bias_ij),
-             ptr(out), C, ptr(lse), n, n_bias_windows, heads, float(scale), dtype_code(x),
+        call("pswin_attn_fwd", x, ctypes.c_void_p(qp), ctypes.c_void_p(kp), ctypes.c_void_p(vp), ld,
+             ptr(None if dist is None else dist.fwd), 0 if dist is None else dist.n, ptr(alpha), ptr(beta),
+             ptr(None if mask is None else mask.fwd), 0 if mask is None else mask.n, ptr(out), C, ptr(lse),
+             int(chunks or 0), n, n_bias_windows, heads, float(scale), dtype_code(x),
              algo_bytes=n * heads * 4 * WTOK * _lib.HEAD_DIM * x.element_size())
         ctx.fused, ctx.heads, ctx.scale, ctx.nb, ctx.n, ctx.C = fused, heads, float(scale), n_bias_windows, n, C
-        ctx.has_dist = dist is not None
-        ctx.save_for_backward(x, k, v, lse, bias_ji, dist)
+        ctx.dist, ctx.mask, ctx.chunks = dist, mask, chunks
+        ctx.save_for_backward(x, k, v, lse, alpha, beta)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         import ctypes
-        x, k, v, lse, bias_ji, dist = ctx.saved_tensors
+        x, k, v, lse, alpha, beta = ctx.saved_tensors
         heads, n, nb, C = ctx.heads, ctx.n, ctx.nb, ctx.C
+        dist, mask = ctx.dist, ctx.mask
         dout = dout.contiguous()
         es = x.element_size()
         if ctx.fused:
@@ -355,28 +391,32 @@ class _WindowAttention(torch.autograd.Function):
             dqp, dkp, dvp = dx.data_ptr(), dk.data_ptr(), dv.data_ptr()
         need_tables = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
         lib = _lib.load()
-        chunks = lib.pswin_attn_suggest_chunks(n, nb, heads)
-        dbias = (torch.empty(chunks * nb, heads, WPAD, WPAD, dtype=torch.float32, device=x.device)
-                 if need_tables else None)
-        call("pswin_attn_bwd", x, ctypes.c_void_p(qp), ctypes.c_void_p(kp), ctypes.c_void_p(vp), ld, ptr(bias_ji),
-             ptr(dout), C, ptr(lse), ctypes.c_void_p(dqp), ctypes.c_void_p(dkp), ctypes.c_void_p(dvp), ld,
-             ptr(dbias), chunks, n, nb, heads, ctx.scale, dtype_code(x),
+        chunks = ctx.chunks or lib.pswin_attn_suggest_chunks(n, nb, heads, 1)
+        dalpha = dbeta = gsum = None
+        if need_tables:
+            gsum = torch.empty(chunks * nb, heads, WPAD, WPAD, dtype=torch.float32, device=x.device)
+        call("pswin_attn_bwd", x, ctypes.c_void_p(qp), ctypes.c_void_p(kp), ctypes.c_void_p(vp), ld,
+             ptr(None if dist is None else dist.bwd), 0 if dist is None else dist.n, ptr(alpha), ptr(beta),
+             ptr(None if mask is None else mask.bwd), 0 if mask is None else mask.n, ptr(dout), C, ptr(lse),
+             ctypes.c_void_p(dqp), ctypes.c_void_p(dkp), ctypes.c_void_p(dvp), ld, ptr(gsum),
+             chunks, n, nb, heads, ctx.scale, dtype_code(x),
              algo_bytes=n * heads * 7 * WTOK * _lib.HEAD_DIM * x.element_size())
-        dalpha = dbeta = None
         if need_tables:
             dbeta = torch.empty(169, heads, dtype=torch.float32, device=x.device)
-            dalpha = torch.empty_like(dbeta) if ctx.has_dist else None
-            ws = torch.empty(lib.pswin_attn_bias_bwd_workspace(heads), dtype=torch.float32, device=x.device)
-            call("pswin_attn_bias_bwd", x, ptr(dbias), chunks * nb, nb, ptr(dist), 0 if dist is None else dist.shape[0],
-                 heads, ptr(dalpha), ptr(dbeta), ptr(ws))
-        return dx, dk, dv, dalpha, dbeta, None, None, None, None, None
+            dalpha = torch.empty_like(dbeta) if dist is not None else None
+            ws = torch.empty(lib.pswin_attn_table_grads_workspace(heads), dtype=torch.float32, device=x.device)
+            call("pswin_attn_table_grads", x, ptr(gsum), chunks * nb, nb, ptr(None if dist is None else dist.bwd),
+                 0 if dist is None else dist.n, heads, ptr(dalpha), ptr(dbeta), ptr(ws))
+        return dx, dk, dv, dalpha, dbeta, None, None, None, None, None, None
 
 
-def window_attention(qkv, alpha, beta, dist, mask, heads, scale, n_bias_windows, k=None, v=None):
+def window_attention(qkv, alpha, beta, dist, mask, heads, scale, n_bias_windows, k=None, v=None, chunks=None):
     """BasicWindowAttention.forward between qkv and proj (HOT:288-308).
 
     qkv: [n*49, 3C] (or q with k, v given: three [n*49, C]); alpha/beta: [169, heads] f32 tables;
-    dist: [nW, 49, 49] f32 great-circle table or None (planar: beta only, HOT:257-258);
-    mask: f32 [nM, 49, 49] or None; window n uses bias tile n % n_bias_windows.  Returns [n*49, C].
+    dist: great-circle table, a [nW, 49, 49] f32 tensor or a prebuilt ``Tiles`` (None in planar mode: beta only,
+    HOT:257-258); mask: f32 [nM, 49, 49] tensor / ``Tiles`` / None; window n uses bias window n % n_bias_windows.
+    chunks: work items per bias window (None = library heuristic).  Returns [n*49, C].
     """
-    return _WindowAttention.apply(qkv, k, v, alpha, beta, dist, mask, heads, scale, n_bias_windows)
+    return _WindowAttention.apply(qkv, k, v, alpha, beta, _as_tiles(dist), _as_tiles(mask), heads, scale,
+                                  n_bias_windows, chunks)

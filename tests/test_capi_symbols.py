@@ -33,8 +33,8 @@ def test_library_exports_every_declared_symbol():
     assert lib.pswin_window_grid(0, 128, 256, ctypes.byref(hp), ctypes.byref(wp), ctypes.byref(nw)) == 0
     assert (hp.value, wp.value, nw.value) == (133, 259, 703)
     assert lib.pswin_window_grid(7, 1, 1, None, None, None) == -1    # PSWIN_ERR_ARG
-    assert lib.pswin_attn_suggest_chunks(8 * 703, 703, 3) == 2
-    assert lib.pswin_attn_bias_bwd_workspace(3) > 0
+    assert lib.pswin_attn_suggest_chunks(8 * 703, 703, 3, 0) == 1 and lib.pswin_attn_suggest_chunks(8 * 15, 15, 24, 1) == 2
+    assert lib.pswin_attn_table_grads_workspace(3) > 0
 
 
 def test_product_never_imports_the_oracle():

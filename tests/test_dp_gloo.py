@@ -36,7 +36,7 @@ def _local_grads(rank):
     return {k: (p.grad.clone() if p.grad is not None else torch.zeros_like(p)) for k, p in m.named_parameters()}, m
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, pack=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank))
     from panoswintransformerobjectdetection_amd.dp import GradReducer, init_distributed
@@ -44,11 +44,13 @@ def _worker(rank, world, port, q):
     assert (r, w) == (rank, world)
     torch.manual_seed(0 if rank == 0 else 77)            # different initial weights: broadcast must fix that
     m = _Net()
-    red = GradReducer(m, bucket_mb=0.0005)               # tiny buckets -> several collectives
+    red = GradReducer(m, bucket_mb=0.0005, pack=pack)    # tiny buckets -> several collectives
     red.broadcast_parameters(m)
     for _ in range(2):                                   # two steps: hooks / counters must re-arm
         red.zero_grad()
         m(_inputs(rank)).square().mean().backward()
+        if pack:
+            red.pack_grads()
         red.finish()
     q.put((rank, {k: p.grad.numpy().copy() for k, p in m.named_parameters()}, len(red.buckets),
            m.bn.running_mean.numpy().copy()))                      # numpy: pickled by value, no fd passing
@@ -56,7 +58,11 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_gradient_average():
+import pytest
+
+
+@pytest.mark.parametrize("pack", [False, True])
+def test_two_rank_gradient_average(pack):
     world = 2
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -64,7 +70,7 @@ def test_two_rank_gradient_average():
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, pack)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])

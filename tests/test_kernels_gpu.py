@@ -224,10 +224,12 @@ def _attn_oracle(x, alpha, beta, dist, mask, gout, heads, n_rep, nW):
     return out.detach(), x.grad, alpha.grad, beta.grad
 
 
-@pytest.mark.parametrize("n_rep,nW,heads,pano,mask_kind", [(2, 3, 2, True, 0), (1, 5, 1, False, 0), (2, 3, 3, False, 3),
-                                                           (2, 3, 2, False, 4), (3, 4, 6, True, 3), (8, 15, 24, True, 0)])
+@pytest.mark.parametrize("n_rep,nW,heads,pano,mask_kind,chunks", [
+    (2, 3, 2, True, 0, None), (1, 5, 1, False, 0, None), (2, 3, 3, False, 3, None), (2, 3, 2, False, 4, None),
+    (3, 4, 6, True, 3, None), (8, 15, 24, True, 0, None),
+    (4, 3, 2, True, 0, 1), (6, 5, 3, True, 3, 2), (3, 2, 1, False, 0, 1)])      # batch loops longer than 1 (prefetch path)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_window_attention_fwd_bwd(ops, n_rep, nW, heads, pano, mask_kind, dtype):
+def test_window_attention_fwd_bwd(ops, n_rep, nW, heads, pano, mask_kind, chunks, dtype):
     x, alpha, beta, dist, mask, gout = _attn_case(n_rep, nW, heads, pano, mask_kind, f"{n_rep}{nW}{heads}")
     if dtype == torch.bfloat16:
         x = x.to(dtype).float()          # the oracle sees the same rounded inputs
@@ -237,7 +239,8 @@ def test_window_attention_fwd_bwd(ops, n_rep, nW, heads, pano, mask_kind, dtype)
     ad, bd = alpha.to(DEV).requires_grad_(True), beta.to(DEV).requires_grad_(True)
     maskd = None if mask is None else mask.reshape(-1, 49, 49).to(DEV)
     nb = nW if mask_kind != 4 else n_rep * nW
-    out = ops.window_attention(xd, ad, bd, None if dist is None else dist.to(DEV), maskd, heads, 32 ** -0.5, nb)
+    out = ops.window_attention(xd, ad, bd, None if dist is None else dist.to(DEV), maskd, heads, 32 ** -0.5, nb,
+                               chunks=chunks)
     out.backward(gout.to(DEV).to(dtype))
     # fp32: exact-f32 MFMA, differs from the oracle by summation order only.  bf16: bf16 operands (q*scale, P and
     # dS are rounded to bf16), f32 accumulation.
@@ -265,6 +268,15 @@ def test_window_attention_separate_qkv(ops):
     _, ref_dx, _, _ = _attn_oracle(x, alpha, beta, dist, None, gout, heads, n_rep, nW)
     got = torch.cat([qd.grad, kd.grad, vd.grad], 1).cpu()
     assert torch.allclose(got, ref_dx, rtol=1e-4, atol=2e-5 * ref_dx.abs().max().item())
+
+
+@pytest.mark.parametrize("M,N,dt", [(275576 // 8, 288, torch.bfloat16), (1000, 96, torch.bfloat16), (98, 27648, torch.bfloat16),
+                                    (5, 3072, torch.float32), (4097, 8, torch.float32)])
+def test_colsum(ops, M, N, dt):
+    x = det_uniform((M, N), "colsum").to(dt)
+    ref = x.double().sum(0).float()
+    got = ops.colsum(x.to(DEV)).cpu()
+    assert torch.allclose(got, ref, rtol=1e-4, atol=1e-3)
 
 
 def test_rejects_cpu_and_bad_args(ops):
