@@ -184,7 +184,7 @@ class PanoSwinTransformerBlock(nn.Module, DoubleModeModule):
         y = self.mlp(ops.layer_norm_gather(x, n2.weight, n2.bias, n2.eps, out_dtype=cd), cd)
         if scale is not None:
             y = y * scale.to(y.dtype)[:, None, None]
-        return x + y.to(x.dtype)
+        return x + y                      # fp32 + bf16 promotes inside one kernel
 
 
 class PitchAttentionModule(WindowAttention):
@@ -240,7 +240,7 @@ class PitchAttentionModule(WindowAttention):
         # the reference overwrites its own shortcut with LN(x) (in-place norm on a view, HOT:1154-1155): residual = xn
         x = ops.window_scatter_add(att, xn, wmap, inv, None)
         y = self.mlp(ops.layer_norm_gather(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, out_dtype=cd), cd)
-        return x + y.to(x.dtype)
+        return x + y
 
 
 class PatchMerging(nn.Module):

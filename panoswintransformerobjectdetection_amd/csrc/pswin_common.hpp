@@ -65,23 +65,29 @@ __device__ inline void store4(void* base, size_t elem_off, f32x4 v) {
     }
 }
 
-// out[c] = sum_r part[r][c] (r in fixed order: bitwise reproducible).  64 columns x 16 row lanes per block.
+// out[c] = sum_r part[r][c] (r in fixed order: bitwise reproducible).  16 columns x 64 row lanes per block, so that
+// even 512 partial rows are only 8 (independent) loads deep per thread: this stage is pure latency.
 __global__ static void colsum_kernel(const float* __restrict__ part, int R, int N, float* __restrict__ out) {
-    __shared__ float red[16][64];
-    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    __shared__ float red[64][16];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (c < N) {
         int r = rl;
-        for (; r + 48 < R; r += 64) {
+        for (; r + 192 < R; r += 256) {
             s0 += part[(size_t)r * N + c];
-            s1 += part[(size_t)(r + 16) * N + c];
-            s2 += part[(size_t)(r + 32) * N + c];
-            s3 += part[(size_t)(r + 48) * N + c];
+            s1 += part[(size_t)(r + 64) * N + c];
+            s2 += part[(size_t)(r + 128) * N + c];
+            s3 += part[(size_t)(r + 192) * N + c];
         }
-        for (; r < R; r += 16) s0 += part[(size_t)r * N + c];
+        for (; r < R; r += 64) s0 += part[(size_t)r * N + c];
     }
     red[rl][cl] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (rl < 16) {      // 16 x 16 threads finish: thread (rl, cl) sums rows rl, rl+16, rl+32, rl+48, then a 16-lane tree
+        float s = (red[rl][cl] + red[rl + 16][cl]) + (red[rl + 32][cl] + red[rl + 48][cl]);
+        red[rl][cl] = s;
+    }
     __syncthreads();
     if (rl == 0 && c < N) {
         float s = 0.f;
@@ -92,7 +98,7 @@ __global__ static void colsum_kernel(const float* __restrict__ part, int R, int 
 }
 
 inline void launch_colsum(const float* part, int R, int N, float* out, hipStream_t st) {
-    hipLaunchKernelGGL(colsum_kernel, dim3((N + 63) / 64), dim3(1024), 0, st, part, R, N, out);
+    hipLaunchKernelGGL(colsum_kernel, dim3((N + 15) / 16), dim3(1024), 0, st, part, R, N, out);
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }

@@ -309,7 +309,53 @@ __global__ __launch_bounds__(256) void rowsum_partial_kernel(const void* __restr
     }
 }
 
+// Short matrices (M <= 1024 rows: split-K partials): one pass.  A block is 32 column groups x 8 row lanes; the row
+// lanes are combined through LDS in a fixed order; no second launch.
+template <int DT>
+__global__ __launch_bounds__(256) void rowsum_direct_kernel(const void* __restrict__ x, int M, int N, int vpr,
+                                                            float* __restrict__ out) {
+    constexpr int VE = (DT == PSWIN_BF16) ? 8 : 4;
+    __shared__ float red[8][32][VE];
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int cg = blockIdx.x * 32 + cl;
+    float acc[VE];
+#pragma unroll
+    for (int e = 0; e < VE; ++e) acc[e] = 0.f;
+    if (cg < vpr) {
+#pragma unroll 4
+        for (int r = rl; r < M; r += 8) {
+            if constexpr (DT == PSWIN_BF16) {
+                const u32x4 raw = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(x) +
+                                                                  (size_t)r * N + (size_t)cg * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[2 * e] += __builtin_bit_cast(float, raw[e] << 16);
+                    acc[2 * e + 1] += __builtin_bit_cast(float, raw[e] & 0xffff0000u);
+                }
+            } else {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(x) + (size_t)r * N +
+                                                                (size_t)cg * 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] += v[e];
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < VE; ++e) red[rl][cl][e] = acc[e];
+    __syncthreads();
+    if (rl == 0 && cg < vpr) {
+#pragma unroll
+        for (int e = 0; e < VE; ++e) {
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += red[q][cl][e];
+            out[(size_t)cg * VE + e] = s;
+        }
+    }
+}
+
 constexpr int ROWSUM_MAX_BLOCKS = 512;
+constexpr int ROWSUM_DIRECT_MAX_ROWS = 1024;
 
 inline int rowsum_blocks(long long M, int N, int dtype) {
     const int ve = dtype == PSWIN_BF16 ? 8 : 4;
@@ -336,6 +382,15 @@ extern "C" int pswin_colsum(const void* x, int dtype, long long M, int N, float*
     PSWIN_CHECK_ARG(N % 8 == 0 && aligned16(x));
     const int ve = dtype == PSWIN_BF16 ? 8 : 4;
     const int vpr = N / ve;
+    if (M <= ROWSUM_DIRECT_MAX_ROWS && vpr >= 32 * 64) {       // >= 64 blocks of column groups: one pass is enough
+        if (dtype == PSWIN_BF16)
+            hipLaunchKernelGGL(rowsum_direct_kernel<PSWIN_BF16>, dim3((vpr + 31) / 32), dim3(256), 0,
+                               (hipStream_t)stream, x, (int)M, N, vpr, out);
+        else
+            hipLaunchKernelGGL(rowsum_direct_kernel<PSWIN_F32>, dim3((vpr + 31) / 32), dim3(256), 0,
+                               (hipStream_t)stream, x, (int)M, N, vpr, out);
+        PSWIN_LAUNCH_RET();
+    }
     const int vprb = vpr < 256 ? vpr : 256;
     const int ychunks = (vpr + vprb - 1) / vprb;
     const int blocks = rowsum_blocks(M, N, dtype);

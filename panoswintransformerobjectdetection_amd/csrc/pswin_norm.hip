@@ -201,23 +201,25 @@ __global__ __launch_bounds__(THREADS) void ln_bwd_kernel(const void* __restrict_
     }
 }
 
-// out_a[c] = sum_r part[r][c], out_b[c] = sum_r part[r][C + c]  (rows of 2C floats)
+// out_a[c] = sum_r part[r][c], out_b[c] = sum_r part[r][C + c]  (rows of 2C floats); 16 columns x 64 row lanes
 __global__ void colsum2_kernel(const float* __restrict__ part, int R, int C, float* __restrict__ out_a,
                                float* __restrict__ out_b) {
-    __shared__ float red[16][64];
-    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    __shared__ float red[64][16];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     const int N = 2 * C;
     float s0 = 0.f, s1 = 0.f;
     if (c < N) {
         int r = rl;
-        for (; r + 16 < R; r += 32) {
+        for (; r + 64 < R; r += 128) {
             s0 += part[(size_t)r * N + c];
-            s1 += part[(size_t)(r + 16) * N + c];
+            s1 += part[(size_t)(r + 64) * N + c];
         }
-        for (; r < R; r += 16) s0 += part[(size_t)r * N + c];
+        for (; r < R; r += 64) s0 += part[(size_t)r * N + c];
     }
     red[rl][cl] = s0 + s1;
+    __syncthreads();
+    if (rl < 16) red[rl][cl] = (red[rl][cl] + red[rl + 16][cl]) + (red[rl + 32][cl] + red[rl + 48][cl]);
     __syncthreads();
     if (rl == 0 && c < N) {
         float s = 0.f;
@@ -229,7 +231,7 @@ __global__ void colsum2_kernel(const float* __restrict__ part, int R, int C, flo
 }
 
 inline void launch_colsum_2(const float* part, int R, int C, float* out_a, float* out_b, hipStream_t st) {
-    hipLaunchKernelGGL(colsum2_kernel, dim3((2 * C + 63) / 64), dim3(1024), 0, st, part, R, C, out_a, out_b);
+    hipLaunchKernelGGL(colsum2_kernel, dim3((2 * C + 15) / 16), dim3(1024), 0, st, part, R, C, out_a, out_b);
 }
 
 // up to 4 chunks of 4 elements per lane (8 for rows wider than 1024 elements: PatchMerging of C >= 384)
