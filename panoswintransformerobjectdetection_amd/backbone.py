@@ -114,11 +114,14 @@ class _LinearSplitK(torch.autograd.Function):
     explicit split-K, 55-75 us) whose fp32 partial sum also removes the bf16 -> fp32 gradient cast."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias):
-        wb = weight.to(x.dtype)
+    def forward(ctx, x, weight, bias, w_lp, b_lp):
+        # w_lp / b_lp: this step's bf16 copies of the fp32 master parameters (refreshed by ONE multi-tensor cast per
+        # forward, see SimplePanoSwinTransformer._refresh_lowp); gradients go to the fp32 masters.
+        wb = w_lp if w_lp is not None else weight.to(x.dtype)
         ctx.save_for_backward(x, wb)
         ctx.has_bias = bias is not None
-        return F.linear(x, wb, None if bias is None else bias.to(x.dtype))
+        bb = None if bias is None else (b_lp if b_lp is not None else bias.to(x.dtype))
+        return F.linear(x, wb, bb)
 
     @staticmethod
     def backward(ctx, dy):
@@ -134,7 +137,7 @@ class _LinearSplitK(torch.autograd.Function):
         else:
             dw = (dy.t() @ x).float()
         db = ops.colsum(dy) if ctx.has_bias else None
-        return dx, dw, db
+        return dx, dw, db, None, None
 
 
 def _linear(x, lin, cd):
@@ -143,7 +146,9 @@ def _linear(x, lin, cd):
         return F.linear(x.float(), lin.weight, lin.bias)
     shp = x.shape
     x2 = x.to(cd).reshape(-1, shp[-1])
-    return _LinearSplitK.apply(x2, lin.weight, lin.bias).view(*shp[:-1], lin.weight.shape[0])
+    lp = lin.__dict__.get("_lowp")
+    w_lp, b_lp = lp if lp is not None else (None, None)
+    return _LinearSplitK.apply(x2, lin.weight, lin.bias, w_lp, b_lp).view(*shp[:-1], lin.weight.shape[0])
 
 
 class PanoSwinTransformerBlock(nn.Module, DoubleModeModule):
@@ -182,9 +187,8 @@ class PanoSwinTransformerBlock(nn.Module, DoubleModeModule):
         x = ops.window_scatter_add(att, x, wmap, inv, scale)                      # shortcut + DropPath(attn)
         n2 = self.norm2
         y = self.mlp(ops.layer_norm_gather(x, n2.weight, n2.bias, n2.eps, out_dtype=cd), cd)
-        if scale is not None:
-            y = y * scale.to(y.dtype)[:, None, None]
-        return x + y                      # fp32 + bf16 promotes inside one kernel
+        ident = ops.identity_map(S, dev)                                          # x + DropPath(mlp): one row kernel
+        return ops.window_scatter_add(y, x, ident, ident, scale)
 
 
 class PitchAttentionModule(WindowAttention):
@@ -240,7 +244,8 @@ class PitchAttentionModule(WindowAttention):
         # the reference overwrites its own shortcut with LN(x) (in-place norm on a view, HOT:1154-1155): residual = xn
         x = ops.window_scatter_add(att, xn, wmap, inv, None)
         y = self.mlp(ops.layer_norm_gather(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, out_dtype=cd), cd)
-        return x + y
+        ident = ops.identity_map(S, dev)
+        return ops.window_scatter_add(y, x, ident, ident, None)
 
 
 class PatchMerging(nn.Module):
@@ -415,6 +420,24 @@ class SimplePanoSwinTransformer(nn.Module, DoubleModeModule):
         else:
             raise TypeError('pretrained must be a str or None')
 
+    @torch.no_grad()
+    def _refresh_lowp(self, cd):
+        """bf16 copies of every Linear weight / bias on the path, refreshed by one multi-tensor cast per forward
+        (instead of ~100 small cast kernels); plain attributes, never part of the state dict."""
+        lins = [m for m in self.modules() if isinstance(m, nn.Linear) and m is not getattr(self, "abs_encoder", None)]
+        src, dst = [], []
+        for m in lins:
+            lp = m.__dict__.get("_lowp")
+            if lp is None or lp[0].device != m.weight.device or lp[0].dtype != cd:
+                lp = (torch.empty_like(m.weight, dtype=cd), None if m.bias is None else torch.empty_like(m.bias, dtype=cd))
+                m.__dict__["_lowp"] = lp
+            src.append(m.weight)
+            dst.append(lp[0])
+            if m.bias is not None:
+                src.append(m.bias)
+                dst.append(lp[1])
+        torch._foreach_copy_(dst, src)
+
     def forward(self, x_bchw, pano_ratio_v=None):
         if pano_ratio_v is not None:
             warnings.warn("Parameter pano_ratio_v for is deprecated! Please set it to None!")
@@ -424,6 +447,8 @@ class SimplePanoSwinTransformer(nn.Module, DoubleModeModule):
         if not x_bchw.is_cuda:
             raise PswinError("SimplePanoSwinTransformer (MI355X build) needs its input on a HIP device")
         cd = self.compute_dtype
+        if cd != torch.float32:
+            self._refresh_lowp(cd)
         x, Wh, Ww = self.patch_embed(x_bchw.float(), cd)
         if self.pano_mode and self.ape:
             feat = ops.abs_pos_features(Wh, Ww, x.device)                               # HOT:926-934

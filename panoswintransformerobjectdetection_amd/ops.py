@@ -40,6 +40,14 @@ def window_maps(pano, H, W, shift, device):
     return _CACHE[key]
 
 
+def identity_map(S, device):
+    """int32 arange(S): the row movers with this map are plain (scaled, residual-added, dtype-converting) row copies."""
+    key = ("ident", S, _dev_key(device))
+    if key not in _CACHE:
+        _CACHE[key] = torch.arange(S, dtype=torch.int32, device=device)
+    return _CACHE[key]
+
+
 def planar_mask(H, W, shift, device):
     """BasicLayer._get_attention_mask (HOT:664-688): f32 [nW, 49, 49] of 0 / -100."""
     key = ("mask", H, W, shift, _dev_key(device))
