@@ -89,18 +89,6 @@ __device__ inline Frag<DT> load_frag(const void* base, size_t off, bool valid) {
     return f;
 }
 
-template <int DT>
-__device__ inline Frag<DT> scale_frag(Frag<DT> f, float s) {
-    if constexpr (DT == PSWIN_BF16) {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) f.v[i] = (__bf16)((float)f.v[i] * s);   // bf16 q*scale, as torch would round it
-    } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) f.v[i] *= s;
-    }
-    return f;
-}
-
 // two accumulator quads -> the 8-element operand of the next MFMA (k order: lo[0..3], hi[0..3])
 template <int DT>
 __device__ inline Frag<DT> pack_frag(f32x4 lo, f32x4 hi) {
@@ -270,9 +258,11 @@ __device__ inline void load_tables(const AttnArgs& a, int h, int lane, float* ta
 // bias quad for query index base qi (4 consecutive when QUERY_ON_REGS) / key index base kj.
 // QUERY_ON_REGS = false (forward):  i = qi fixed, j = kj + e          tile row = i, quad along j
 // QUERY_ON_REGS = true  (backward): i = qi + e,   j = kj fixed        tile row = j (transposed tiles), quad along i
+// The result is bias / scale: the kernels run the MFMAs on the UNSCALED q (score' = q.k + bias/scale) and fold the
+// scale into the exp2 argument, which removes the per-image q*scale pass.  Branch-free (selects only).
 template <bool QUERY_ON_REGS>
 __device__ inline f32x4 bias_quad(const float* dtile, const float* mtile, const float* tab_a, const float* tab_b,
-                                  int qi, int kj) {
+                                  int qi, int kj, float inv_scale) {
     const int row = QUERY_ON_REGS ? kj : qi, col = QUERY_ON_REGS ? qi : kj;
     f32x4 d4 = {0.f, 0.f, 0.f, 0.f}, m4 = {0.f, 0.f, 0.f, 0.f};
     if (dtile) d4 = *reinterpret_cast<const f32x4*>(dtile + row * PADT + col);
@@ -281,19 +271,16 @@ __device__ inline f32x4 bias_quad(const float* dtile, const float* mtile, const 
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int i = QUERY_ON_REGS ? qi + e : qi, j = QUERY_ON_REGS ? kj : kj + e;
-        float val;
-        if (j >= TOK) {
-            val = -INFINITY;                    // padded key: never receives weight
-        } else if (i >= TOK) {
-            val = 0.f;                          // padded query row: discarded
-        } else {
-            const int idx = rel_a(i) - rel_b(j);
-            // same rounding sequence as the reference: (d * alpha + beta) [+ mask]   (HOT:255-256, 294, 301)
-            val = tab_b[idx];
-            if (dtile) val = __fadd_rn(__fmul_rn(d4[e], tab_a[idx]), val);
-            if (mtile) val = __fadd_rn(val, m4[e]);
-        }
-        r[e] = val;
+        const bool real = (i < TOK) & (j < TOK);
+        int idx = rel_a(i) - rel_b(j);
+        idx = real ? idx : 0;
+        // same rounding sequence as the reference: (d * alpha + beta) [+ mask]   (HOT:255-256, 294, 301)
+        float val = tab_b[idx];
+        if (dtile) val = __fadd_rn(__fmul_rn(d4[e], tab_a[idx]), val);
+        if (mtile) val = __fadd_rn(val, m4[e]);
+        val *= inv_scale;
+        val = (i < TOK) ? val : 0.f;                 // padded query row: discarded
+        r[e] = (j < TOK) ? val : -INFINITY;          // padded key: never receives weight
     }
     return r;
 }
@@ -343,7 +330,9 @@ __global__ __launch_bounds__(64 * WAVES, (DT == PSWIN_BF16 ? 2 : 1)) void attn_f
 
     load_tables(a, h, lane, tab_a, tab_b);
     __builtin_amdgcn_wave_barrier();
-    // bias tile of (wb, h): query on the lane, 4 consecutive keys per quad; lives in VGPRs for the whole batch loop
+    const float inv_scale = 1.0f / a.scale;
+    const float sl2e = a.scale * LOG2E;          // scores are kept unscaled: p = exp2((s' - m') * scale * log2 e)
+    // bias tile of (wb, h) / scale: query on the lane, 4 consecutive keys per quad; in VGPRs for the whole batch loop
     f32x4 bias[4][4];
     {
         const float* dtile = a.dist ? a.dist + (size_t)(wb % a.n_dist) * (PADT * PADT) : nullptr;
@@ -352,7 +341,7 @@ __global__ __launch_bounds__(64 * WAVES, (DT == PSWIN_BF16 ? 2 : 1)) void attn_f
         for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
             for (int tj = 0; tj < 4; ++tj)
-                bias[ti][tj] = bias_quad<false>(dtile, mtile, tab_a, tab_b, 16 * ti + c, 16 * tj + 4 * g);
+                bias[ti][tj] = bias_quad<false>(dtile, mtile, tab_a, tab_b, 16 * ti + c, 16 * tj + 4 * g, inv_scale);
     }
 
     for (int r = 0; r < a.reps_per_chunk; ++r) {
@@ -363,11 +352,9 @@ __global__ __launch_bounds__(64 * WAVES, (DT == PSWIN_BF16 ? 2 : 1)) void attn_f
         // S^T tiles: keys 16 tj + 4 g + e on the accumulator rows, query 16 ti + c on the lane
         f32x4 s4[4][4];
 #pragma unroll
-        for (int ti = 0; ti < 4; ++ti) {
-            const Frag<DT> qs = scale_frag<DT>(cur.q[ti], a.scale);
+        for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
-            for (int tj = 0; tj < 4; ++tj) s4[ti][tj] = mma32<DT>(cur.k[tj], qs, bias[ti][tj]);
-        }
+            for (int tj = 0; tj < 4; ++tj) s4[ti][tj] = mma32<DT>(cur.k[tj], cur.q[ti], bias[ti][tj]);
         // the operand registers are free: request the next image now, its latency hides under softmax + PV
         if (r + 1 < a.reps_per_chunk) load_tiles(r + 1, cur);
         // V^T operand fragments: [k-step s][d tile dt]
@@ -381,9 +368,9 @@ __global__ __launch_bounds__(64 * WAVES, (DT == PSWIN_BF16 ? 2 : 1)) void attn_f
         float m[4], l[4];
 #pragma unroll
         for (int ti = 0; ti < 4; ++ti) {
-            float mm = -INFINITY;
+            float mm = s4[ti][3][0];                 // key tile 3 holds only key 48 (element 0 of group 0): rest is -inf
 #pragma unroll
-            for (int tj = 0; tj < 4; ++tj)
+            for (int tj = 0; tj < 3; ++tj)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) mm = fmaxf(mm, s4[ti][tj][e]);
             m[ti] = mm;
@@ -392,15 +379,19 @@ __global__ __launch_bounds__(64 * WAVES, (DT == PSWIN_BF16 ? 2 : 1)) void attn_f
         for (int ti = 0; ti < 4; ++ti) m[ti] = group_max(m[ti]);
 #pragma unroll
         for (int ti = 0; ti < 4; ++ti) {
-            const float mb = m[ti] * LOG2E;
+            const float mb = -m[ti] * sl2e;
             float ll = 0.f;
 #pragma unroll
             for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float p = __builtin_amdgcn_exp2f(s4[ti][tj][e] * LOG2E - mb);
-                    s4[ti][tj][e] = p;
-                    ll += p;
+                    if (tj == 3 && e > 0) {
+                        s4[ti][tj][e] = 0.f;         // keys 49..63: bias -inf, weight exactly 0
+                    } else {
+                        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s4[ti][tj][e], sl2e, mb));
+                        s4[ti][tj][e] = p;
+                        ll += p;
+                    }
                 }
             l[ti] = ll;
         }
@@ -427,7 +418,7 @@ __global__ __launch_bounds__(64 * WAVES, (DT == PSWIN_BF16 ? 2 : 1)) void attn_f
                 for (int dt = 0; dt < 2; ++dt)
                     store_quad<DT>(a.out, (row0 + i) * (size_t)a.ld_out + h * HD + 16 * dt + 4 * g, o[ti][dt] * inv_l);
             }
-            if (g == 0) a.lse[(win * a.heads + h) * PADT + i] = (i < TOK) ? m[ti] + logf(l[ti]) : INFINITY;
+            if (g == 0) a.lse[(win * a.heads + h) * PADT + i] = (i < TOK) ? __builtin_fmaf(m[ti], a.scale, logf(l[ti])) : INFINITY;
         }
     }
 }
@@ -482,13 +473,15 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_kernel(AttnArgs a) {
 
     load_tables(a, h, lane, tab_a, tab_b);
     __builtin_amdgcn_wave_barrier();
-    // bias in the backward layout: rows i = 16 ti + 4 g + e on the registers, key j = 16 tj + c on the lane
+    const float inv_scale = 1.0f / a.scale;
+    const float sl2e = a.scale * LOG2E;
+    // bias / scale in the backward layout: rows i = 16 ti + 4 g + e on the registers, key j = 16 tj + c on the lane
     f32x4 bias[4][4];
 #pragma unroll
     for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj)
-            bias[ti][tj] = bias_quad<true>(dtile, mtile, tab_a, tab_b, 16 * ti + 4 * g, 16 * tj + c);
+            bias[ti][tj] = bias_quad<true>(dtile, mtile, tab_a, tab_b, 16 * ti + 4 * g, 16 * tj + c, inv_scale);
 
     f32x4 gsum[4][4];   // sum over the batch loop of dS
 #pragma unroll
@@ -506,7 +499,6 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_kernel(AttnArgs a) {
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            cur.q[t] = scale_frag<DT>(cur.q[t], a.scale);
             lds_write_frag<DT, HD>(qimg, 16 * t + c, 8 * g, cur.q[t]);
             lds_write_frag<DT, HD>(kimg, 16 * t + c, 8 * g, cur.k[t]);
             lds_write_frag<DT, HD>(doimg, 16 * t + c, 8 * g, cur.d[t]);
@@ -527,17 +519,20 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_kernel(AttnArgs a) {
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
                 const int ti = 2 * s + tt;
-                const f32x4 lse4 = *reinterpret_cast<const f32x4*>(lse_row + 16 * ti + 4 * g);
+                f32x4 lse4 = *reinterpret_cast<const f32x4*>(lse_row + 16 * ti + 4 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) lse4[e] = -lse4[e] * LOG2E;       // p = exp2(s' * scale*log2e - lse*log2e)
                 f32x4 delta = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int tj = 0; tj < 4; ++tj) {
-                    const f32x4 sc = mma32<DT>(cur.q[ti], cur.k[tj], bias[ti][tj]);                  // S[i][j] + bias
+                    const f32x4 sc = mma32<DT>(cur.q[ti], cur.k[tj], bias[ti][tj]);                  // (S + bias) / scale
                     const f32x4 dp = mma32<DT>(cur.d[ti], cur.v[tj], f32x4{0.f, 0.f, 0.f, 0.f});     // dP[i][j]
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        const float p = __builtin_amdgcn_exp2f((sc[e] - lse4[e]) * LOG2E);
+                        // query tile 3 holds only query 48 (row e = 0 of group 0); its other rows have lse = +inf
+                        const float p = (ti == 3 && e > 0) ? 0.f : __builtin_amdgcn_exp2f(__builtin_fmaf(sc[e], sl2e, lse4[e]));
                         p4[tt][tj][e] = p;
-                        delta[e] += p * dp[e];
+                        delta[e] = __builtin_fmaf(p, dp[e], delta[e]);
                     }
                     ds4[tt][tj] = dp;
                 }
@@ -580,7 +575,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_kernel(AttnArgs a) {
                 for (int dt = 0; dt < 2; ++dt) {
                     const size_t off = (row0 + j) * (size_t)a.ld_dqkv + h * HD + 16 * dt + 4 * g;
                     store_quad<DT>(a.dv, off, dv[dt][tj]);
-                    store_quad<DT>(a.dk, off, dk[dt][tj]);
+                    store_quad<DT>(a.dk, off, dk[dt][tj] * a.scale);
                 }
             }
         }
