@@ -176,8 +176,18 @@ def main():
         dom = max(("pswin_attn_fwd", "pswin_attn_bwd"), key=lambda n: stats.get(n, {}).get("ms_per_step", 0.0))
         recs = kern[dom]
         achieved = sum(r[1] for r in recs) / (sum(r[0] for r in recs) * 1e-3) / 1e9
+        # HBM bytes per launch from the PMC counters (FETCH_SIZE x 2 + WRITE_SIZE, separate rocprofv3 --pmc passes of this
+        # same command, summarised by tools/pmc_summary.py into profiles/pmc_traffic.json); None when not collected.
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+                traffic = round(json.load(f)["kernels"][dom]["hbm_bytes_per_launch"])
+        except (OSError, KeyError, ValueError):
+            pass
+        algo_per_launch = sum(r[1] for r in recs) / len(recs)
         roofline = {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": round(algo_per_launch),
                     "avg_launch_us": stats[dom]["avg_us"], "kernels": stats}
         line = {
             "metric": "panoramas/sec PanoSwin-T 512x1024 fwd+bwd", "value": round(value, 2), "unit": "panoramas/s",

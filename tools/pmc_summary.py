@@ -1,0 +1,38 @@
+"""Combine two rocprofv3 --pmc runs of bench.py (FETCH_SIZE, WRITE_SIZE) into per-kernel HBM traffic per launch.
+
+usage: python tools/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
+
+Corrections (MI355X_MICROARCH.md, HBM section): counters are in KiB; on gfx950 FETCH_SIZE reports exactly half of
+the bytes of a wide (16 B/lane) coalesced streaming read, which is how these kernels read -> fetch x 2.  WRITE_SIZE
+is exact for 16 B/lane streaming stores.  The first launches (warm-up, lazily built tables) are included; they are
+the same kernels on the same shapes.
+"""
+import csv, json, sys
+from collections import defaultdict
+
+KERNELS = {"attn_fwd_kernel": "pswin_attn_fwd", "attn_bwd_kernel": "pswin_attn_bwd", "ln_fwd_kernel": "pswin_ln_gather_fwd",
+           "ln_bwd_kernel": "pswin_ln_gather_bwd", "window_gather_kernel": "pswin_window_gather",
+           "window_scatter_add_kernel": "pswin_window_scatter_add"}
+
+
+def collect(path, counter):
+    acc = defaultdict(lambda: [0.0, 0])
+    for r in csv.DictReader(open(path)):
+        if r["Counter_Name"] != counter:
+            continue
+        for key, name in KERNELS.items():
+            if key in r["Kernel_Name"]:
+                acc[name][0] += float(r["Counter_Value"]) * 1024.0
+                acc[name][1] += 1
+    return acc
+
+
+fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
+out = {}
+for name in sorted(set(fetch) | set(write)):
+    f, nf = fetch.get(name, [0, 1])
+    w, nw = write.get(name, [0, 1])
+    out[name] = {"launches": nf, "fetch_bytes_per_launch_raw": f / max(nf, 1), "fetch_bytes_per_launch_corrected": 2 * f / max(nf, 1),
+                 "write_bytes_per_launch": w / max(nw, 1), "hbm_bytes_per_launch": 2 * f / max(nf, 1) + w / max(nw, 1)}
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on bench.py", "kernels": out}, open(sys.argv[3], "w"), indent=1)
+print(json.dumps(out, indent=1))
