@@ -153,6 +153,23 @@ int pswin_patch_merge_gather(const void* x, int x_dtype, void* out, int out_dtyp
 int pswin_patch_merge_scatter(const void* dout, int out_dtype, void* dx, int x_dtype, int B, int H, int W, int C,
                               void* stream);
 
+/* BatchNorm2d + ReLU of the PatchEmbed stem (nn.BatchNorm2d + nn.ReLU after each 3x3 convolution, HOT:742-748) on a
+ * channels-last activation viewed as rows y[M = N*H*W, C]:  z = relu((y - mean) * rstd * gamma + beta).
+ * train != 0: mean / biased variance of the batch (nn.BatchNorm2d training semantics), running_mean / running_var
+ * (may be NULL) updated in place with `momentum` and the unbiased variance; train == 0: the running statistics.
+ * save_mean, save_rstd: f32 [C], kept for the backward pass.  y, z: dtype f32 or bf16, C % 8 == 0, C <= 1024.
+ * workspace: f32, pswin_bn_workspace(C) elements. */
+int pswin_bn_workspace(int C);
+int pswin_bn_relu_fwd(const void* y, int dtype, const float* gamma, const float* beta, float eps, float momentum,
+                      int train, float* running_mean, float* running_var, void* z, float* save_mean, float* save_rstd,
+                      float* workspace, long long M, int C, void* stream);
+
+/* Its backward: g = dz * [z > 0];  dy = gamma * rstd * (g - mean(g) - xhat * mean(g * xhat)) (train) or
+ * gamma * rstd * g (eval);  dgamma = sum g * xhat, dbeta = sum g (fixed summation order). */
+int pswin_bn_relu_bwd(const void* dz, const void* y, int dtype, const float* gamma, const float* beta,
+                      const float* save_mean, const float* save_rstd, int train, void* dy, float* dgamma, float* dbeta,
+                      float* workspace, long long M, int C, void* stream);
+
 /* Column sums of a row-major [M, N] matrix in fp32: out[n] = sum_m x[m][n] (fixed summation order).  The bias
  * gradient of every Linear on the path (autograd of nn.Linear, HOT:50-52, 236, 323) and the reduction of split-K
  * weight-gradient partials.  N % 8 == 0; workspace: f32, pswin_colsum_workspace(M, N, dtype) elements. */

@@ -342,7 +342,12 @@ class PatchEmbed(nn.Module):
             for mod in self.proj:
                 if isinstance(mod, nn.Conv2d):
                     x = _ChannelBias.apply(F.conv2d(x, mod.weight, None, mod.stride, mod.padding), mod.bias)
-                else:
+                elif isinstance(mod, nn.BatchNorm2d):
+                    if mod.num_features % 8 == 0:
+                        x = ops.batch_norm_relu(x, mod, self.training)      # BN + the ReLU that follows, one HIP op
+                    else:                                                   # odd widths (embed_dim % 24 != 0): MIOpen
+                        x = F.relu(mod(x))
+                elif not isinstance(mod, nn.ReLU):
                     x = mod(x)
         B, C, Wh, Ww = x.shape
         tok = x.permute(0, 2, 3, 1).reshape(B, Wh * Ww, C)          # free for a channels-last tensor

@@ -261,6 +261,48 @@ def layer_norm_patch_merge(x, gamma, beta, eps, H, W, out_dtype=None):
     return _LayerNormPatchMerge.apply(x, gamma, beta, eps, H, W, out_dtype or x.dtype)
 
 
+class _BatchNormReLU(torch.autograd.Function):
+    """nn.BatchNorm2d (batch or running statistics) + ReLU on a channels-last NCHW tensor (HOT:742-748)."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, running_mean, running_var, eps, momentum, train):
+        N, C, H, W = y.shape
+        rows = y.permute(0, 2, 3, 1)
+        assert rows.is_contiguous(), "BatchNorm+ReLU kernel expects a channels-last activation"
+        M = N * H * W
+        z = torch.empty_like(y)                                     # preserves the channels-last strides
+        mean = torch.empty(C, dtype=torch.float32, device=y.device)
+        rstd = torch.empty_like(mean)
+        ws = torch.empty(_lib.load().pswin_bn_workspace(C), dtype=torch.float32, device=y.device)
+        call("pswin_bn_relu_fwd", y, ptr(y), dtype_code(y), ptr(gamma), ptr(beta), float(eps), float(momentum),
+             int(train), ptr(running_mean), ptr(running_var), ptr(z), ptr(mean), ptr(rstd), ptr(ws), M, C)
+        ctx.save_for_backward(y, gamma, beta, mean, rstd)
+        ctx.train = bool(train)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        y, gamma, beta, mean, rstd = ctx.saved_tensors
+        N, C, H, W = y.shape
+        dz = dz.contiguous(memory_format=torch.channels_last)
+        dy = torch.empty_like(y)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        ws = torch.empty(_lib.load().pswin_bn_workspace(C), dtype=torch.float32, device=y.device)
+        call("pswin_bn_relu_bwd", y, ptr(dz), ptr(y), dtype_code(y), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd),
+             int(ctx.train), ptr(dy), ptr(dgamma), ptr(dbeta), ptr(ws), N * H * W, C)
+        return dy, dgamma, dbeta, None, None, None, None, None
+
+
+def batch_norm_relu(y, bn, training):
+    """ReLU(BatchNorm2d(y)) for a channels-last y with the parameters / buffers of the nn.BatchNorm2d module `bn`."""
+    use_batch = training or bn.running_mean is None
+    if use_batch and bn.num_batches_tracked is not None and training:
+        bn.num_batches_tracked.add_(1)
+    momentum = 0.1 if bn.momentum is None else bn.momentum
+    return _BatchNormReLU.apply(y, bn.weight, bn.bias, bn.running_mean if (training or not use_batch) else None,
+                                bn.running_var if (training or not use_batch) else None, bn.eps, momentum, use_batch)
+
+
 def colsum(x2d):
     """fp32 column sums of a [M, N] matrix (N % 8 == 0): bias gradients and split-K partial reductions."""
     x2d = x2d.contiguous()

@@ -270,6 +270,38 @@ def test_window_attention_separate_qkv(ops):
     assert torch.allclose(got, ref_dx, rtol=1e-4, atol=2e-5 * ref_dx.abs().max().item())
 
 
+@pytest.mark.parametrize("C", [32, 64])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("train", [True, False])
+def test_batch_norm_relu(ops, C, dt, train):
+    import torch.nn as nn
+    N, H, W = 2, 37, 53
+    y = (det_uniform((N, C, H, W), "bn:y", 2.0) + det_uniform((1, C, 1, 1), "bn:off", 1.5)).to(dt)
+    gout = det_uniform((N, C, H, W), "bn:g").to(dt)
+    bn_ref = nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn_ref.weight.copy_(det_uniform((C,), "bn:w", 0.5, 1.0)); bn_ref.bias.copy_(det_uniform((C,), "bn:b", 0.5))
+        bn_ref.running_mean.copy_(det_uniform((C,), "bn:rm", 0.3)); bn_ref.running_var.copy_(det_uniform((C,), "bn:rv", 0.3, 1.0))
+    import copy
+    bn_dev = copy.deepcopy(bn_ref).to(DEV)
+    bn_ref.train(train); bn_dev.train(train)
+    yr = y.float().clone().requires_grad_(True)
+    ref = F.relu(bn_ref(yr))
+    (ref * gout.float()).sum().backward()
+    yd = y.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    out = ops.batch_norm_relu(yd, bn_dev, train)
+    assert out.dtype == dt and out.is_contiguous(memory_format=torch.channels_last)
+    out.backward(gout.to(DEV).contiguous(memory_format=torch.channels_last))
+    tol = dict(rtol=1e-4, atol=1e-5) if dt == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    assert torch.allclose(out.float().cpu(), ref, **tol)
+    assert torch.allclose(yd.grad.float().cpu(), yr.grad, rtol=tol["rtol"] * 5, atol=tol["atol"] * 5)
+    assert torch.allclose(bn_dev.weight.grad.cpu(), bn_ref.weight.grad, rtol=1e-3 if dt == torch.float32 else 3e-2, atol=1e-3 * bn_ref.weight.grad.abs().max().item() + (0 if dt == torch.float32 else 0.3))
+    assert torch.allclose(bn_dev.bias.grad.cpu(), bn_ref.bias.grad, rtol=1e-3 if dt == torch.float32 else 3e-2, atol=1e-3 * bn_ref.bias.grad.abs().max().item() + (0 if dt == torch.float32 else 0.3))
+    assert torch.allclose(bn_dev.running_mean.cpu(), bn_ref.running_mean, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(bn_dev.running_var.cpu(), bn_ref.running_var, rtol=1e-4, atol=1e-5)
+    assert int(bn_dev.num_batches_tracked) == int(bn_ref.num_batches_tracked)
+
+
 @pytest.mark.parametrize("M,N,dt", [(275576 // 8, 288, torch.bfloat16), (1000, 96, torch.bfloat16), (98, 27648, torch.bfloat16),
                                     (5, 3072, torch.float32), (4097, 8, torch.float32)])
 def test_colsum(ops, M, N, dt):
