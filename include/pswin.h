@@ -157,11 +157,14 @@ int pswin_patch_merge_scatter(const void* dout, int out_dtype, void* dx, int x_d
  * channels-last activation viewed as rows y[M = N*H*W, C]:  z = relu((y - mean) * rstd * gamma + beta).
  * train != 0: mean / biased variance of the batch (nn.BatchNorm2d training semantics), running_mean / running_var
  * (may be NULL) updated in place with `momentum` and the unbiased variance; train == 0: the running statistics.
+ * mean_offset (may be NULL): a per-channel constant the caller has NOT added to y although the reference adds it in
+ * front of the BatchNorm (the convolution bias, HOT:743/746): it cancels in z and only shifts the tracked mean, so it is
+ * folded into running_mean (train) / subtracted from it (eval) instead of costing a pass over the activation.
  * save_mean, save_rstd: f32 [C], kept for the backward pass.  y, z: dtype f32 or bf16, C % 8 == 0, C <= 1024.
  * workspace: f32, pswin_bn_workspace(C) elements. */
 int pswin_bn_workspace(int C);
-int pswin_bn_relu_fwd(const void* y, int dtype, const float* gamma, const float* beta, float eps, float momentum,
-                      int train, float* running_mean, float* running_var, void* z, float* save_mean, float* save_rstd,
+int pswin_bn_relu_fwd(const void* y, int dtype, const float* gamma, const float* beta, const float* mean_offset,
+                      float eps, float momentum, int train, float* running_mean, float* running_var, void* z, float* save_mean, float* save_rstd,
                       float* workspace, long long M, int C, void* stream);
 
 /* Its backward: g = dz * [z > 0];  dy = gamma * rstd * (g - mean(g) - xhat * mean(g * xhat)) (train) or

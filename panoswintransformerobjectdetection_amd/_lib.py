@@ -36,7 +36,7 @@ _PROTOTYPES = {
     "pswin_patch_merge_gather": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "pswin_patch_merge_scatter": [_vp, _i, _vp, _i, _i, _i, _i, _i, _vp],
     "pswin_bn_workspace": [_i],
-    "pswin_bn_relu_fwd": [_vp, _i, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _vp],
+    "pswin_bn_relu_fwd": [_vp, _i, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _vp],
     "pswin_bn_relu_bwd": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _vp],
     "pswin_colsum_workspace": [ctypes.c_longlong, _i, _i],
     "pswin_colsum": [_vp, _i, ctypes.c_longlong, _i, _vp, _vp, _vp],

@@ -339,12 +339,20 @@ class PatchEmbed(nn.Module):
             x = F.pad(x, (0, 0, 0, ph - H % ph))
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=(cd == torch.bfloat16)):
             x = x.contiguous(memory_format=torch.channels_last)                 # bf16: MIOpen NHWC bf16 convolutions
-            for mod in self.proj:
+            mods = list(self.proj)
+            pending_bias = None
+            for i, mod in enumerate(mods):
                 if isinstance(mod, nn.Conv2d):
-                    x = _ChannelBias.apply(F.conv2d(x, mod.weight, None, mod.stride, mod.padding), mod.bias)
+                    x = F.conv2d(x, mod.weight, None, mod.stride, mod.padding)
+                    nxt = mods[i + 1] if i + 1 < len(mods) else None
+                    if isinstance(nxt, nn.BatchNorm2d) and nxt.num_features % 8 == 0:
+                        pending_bias = mod.bias      # cancels inside the BatchNorm: folded into its running mean only
+                    else:
+                        x = _ChannelBias.apply(x, mod.bias)
                 elif isinstance(mod, nn.BatchNorm2d):
                     if mod.num_features % 8 == 0:
-                        x = ops.batch_norm_relu(x, mod, self.training)      # BN + the ReLU that follows, one HIP op
+                        x = ops.batch_norm_relu(x, mod, self.training, pending_bias)   # BN + ReLU: one HIP op
+                        pending_bias = None
                     else:                                                   # odd widths (embed_dim % 24 != 0): MIOpen
                         x = F.relu(mod(x))
                 elif not isinstance(mod, nn.ReLU):

@@ -124,8 +124,8 @@ __global__ __launch_bounds__(THREADS) void bn_reduce_kernel(const void* __restri
 // sums: [2][C] = (sum y, sum y^2).  Writes mean, rstd, scale = gamma*rstd, shift = beta - mean*scale; updates the
 // running statistics like nn.BatchNorm2d (momentum, unbiased variance).
 __global__ void bn_finalize_kernel(const float* __restrict__ sums, long long M, int C, const float* __restrict__ gamma,
-                                   const float* __restrict__ beta, float eps, float momentum,
-                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   const float* __restrict__ beta, const float* __restrict__ mean_offset, float eps,
+                                   float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ scale,
                                    float* __restrict__ shift) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -140,24 +140,29 @@ __global__ void bn_finalize_kernel(const float* __restrict__ sums, long long M, 
     scale[c] = s;
     shift[c] = beta[c] - (float)m * s;
     if (running_mean) {
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+        // a per-channel constant added in front of BN (the convolution bias) cancels in the output and only moves
+        // the tracked mean: it is applied here instead of in a pass over the activation
+        const float tracked = (float)m + (mean_offset ? mean_offset[c] : 0.f);
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * tracked;
         const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
         running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
     }
 }
 
 // eval mode: statistics are the running ones
-__global__ void bn_eval_params_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+__global__ void bn_eval_params_kernel(int C, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ mean_offset, float eps,
                                       const float* __restrict__ running_mean, const float* __restrict__ running_var,
                                       float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ scale,
                                       float* __restrict__ shift) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     const float r = 1.0f / sqrtf(running_var[c] + eps);
-    mean[c] = running_mean[c];
+    const float m = running_mean[c] - (mean_offset ? mean_offset[c] : 0.f);   // y here excludes the offset
+    mean[c] = m;
     rstd[c] = r;
     scale[c] = gamma[c] * r;
-    shift[c] = beta[c] - running_mean[c] * gamma[c] * r;
+    shift[c] = beta[c] - m * gamma[c] * r;
 }
 
 // scale = gamma * rstd, shift = beta - mean * scale from saved statistics (backward pass)
@@ -270,8 +275,8 @@ inline void sum_partials(const Ws& w, int blocks, int C, hipStream_t st) { launc
 
 extern "C" int pswin_bn_workspace(int C) { return C > 0 ? (MAX_BLOCKS * 2 + 6) * C : PSWIN_ERR_ARG; }
 
-extern "C" int pswin_bn_relu_fwd(const void* y, int dtype, const float* gamma, const float* beta, float eps,
-                                 float momentum, int train, float* running_mean, float* running_var, void* z,
+extern "C" int pswin_bn_relu_fwd(const void* y, int dtype, const float* gamma, const float* beta,
+                                 const float* mean_offset, float eps, float momentum, int train, float* running_mean, float* running_var, void* z,
                                  float* save_mean, float* save_rstd, float* workspace, long long M, int C,
                                  void* stream) {
     PSWIN_CHECK_ARG(y && gamma && beta && z && save_mean && save_rstd && workspace);
@@ -288,11 +293,11 @@ extern "C" int pswin_bn_relu_fwd(const void* y, int dtype, const float* gamma, c
             hipLaunchKernelGGL((bn_reduce_kernel<PSWIN_F32, 0>), dim3(blocks), dim3(THREADS), 0, st, y, nullptr, nullptr,
                                nullptr, nullptr, nullptr, M, C, w.partial);
         sum_partials(w, blocks, C, st);
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, w.sums, M, C, gamma, beta, eps,
-                           momentum, running_mean, running_var, save_mean, save_rstd, w.scale, w.shift);
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, st, w.sums, M, C, gamma, beta,
+                           mean_offset, eps, momentum, running_mean, running_var, save_mean, save_rstd, w.scale, w.shift);
     } else {
-        hipLaunchKernelGGL(bn_eval_params_kernel, dim3((C + 63) / 64), dim3(64), 0, st, C, gamma, beta, eps, running_mean,
-                           running_var, save_mean, save_rstd, w.scale, w.shift);
+        hipLaunchKernelGGL(bn_eval_params_kernel, dim3((C + 63) / 64), dim3(64), 0, st, C, gamma, beta, mean_offset, eps,
+                           running_mean, running_var, save_mean, save_rstd, w.scale, w.shift);
     }
     const int ve = dtype == PSWIN_BF16 ? 8 : 4;
     const long long n_vec = M * (C / ve);

@@ -265,7 +265,7 @@ class _BatchNormReLU(torch.autograd.Function):
     """nn.BatchNorm2d (batch or running statistics) + ReLU on a channels-last NCHW tensor (HOT:742-748)."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, eps, momentum, train):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, eps, momentum, train, pre_bias):
         N, C, H, W = y.shape
         rows = y.permute(0, 2, 3, 1)
         assert rows.is_contiguous(), "BatchNorm+ReLU kernel expects a channels-last activation"
@@ -274,10 +274,11 @@ class _BatchNormReLU(torch.autograd.Function):
         mean = torch.empty(C, dtype=torch.float32, device=y.device)
         rstd = torch.empty_like(mean)
         ws = torch.empty(_lib.load().pswin_bn_workspace(C), dtype=torch.float32, device=y.device)
-        call("pswin_bn_relu_fwd", y, ptr(y), dtype_code(y), ptr(gamma), ptr(beta), float(eps), float(momentum),
+        call("pswin_bn_relu_fwd", y, ptr(y), dtype_code(y), ptr(gamma), ptr(beta), ptr(pre_bias), float(eps), float(momentum),
              int(train), ptr(running_mean), ptr(running_var), ptr(z), ptr(mean), ptr(rstd), ptr(ws), M, C)
         ctx.save_for_backward(y, gamma, beta, mean, rstd)
         ctx.train = bool(train)
+        ctx.pre_bias_shape = None if pre_bias is None else pre_bias.shape
         return z
 
     @staticmethod
@@ -290,17 +291,24 @@ class _BatchNormReLU(torch.autograd.Function):
         ws = torch.empty(_lib.load().pswin_bn_workspace(C), dtype=torch.float32, device=y.device)
         call("pswin_bn_relu_bwd", y, ptr(dz), ptr(y), dtype_code(y), ptr(gamma), ptr(beta), ptr(mean), ptr(rstd),
              int(ctx.train), ptr(dy), ptr(dgamma), ptr(dbeta), ptr(ws), N * H * W, C)
-        return dy, dgamma, dbeta, None, None, None, None, None
+        # a constant added in front of batch-statistics BN has an exactly zero gradient; in eval mode it is sum(dy)
+        dpre = None
+        if ctx.pre_bias_shape is not None:
+            dpre = torch.zeros(ctx.pre_bias_shape, dtype=torch.float32, device=y.device) if ctx.train else \
+                colsum(dy.permute(0, 2, 3, 1).reshape(-1, C))
+        return dy, dgamma, dbeta, None, None, None, None, None, dpre
 
 
-def batch_norm_relu(y, bn, training):
-    """ReLU(BatchNorm2d(y)) for a channels-last y with the parameters / buffers of the nn.BatchNorm2d module `bn`."""
+def batch_norm_relu(y, bn, training, pre_bias=None):
+    """ReLU(BatchNorm2d(y + pre_bias)) for a channels-last y with the parameters / buffers of the nn.BatchNorm2d
+    module `bn`; pre_bias (the convolution bias) is never materialised on the activation."""
     use_batch = training or bn.running_mean is None
     if use_batch and bn.num_batches_tracked is not None and training:
         bn.num_batches_tracked.add_(1)
     momentum = 0.1 if bn.momentum is None else bn.momentum
     return _BatchNormReLU.apply(y, bn.weight, bn.bias, bn.running_mean if (training or not use_batch) else None,
-                                bn.running_var if (training or not use_batch) else None, bn.eps, momentum, use_batch)
+                                bn.running_var if (training or not use_batch) else None, bn.eps, momentum, use_batch,
+                                pre_bias)
 
 
 def colsum(x2d):

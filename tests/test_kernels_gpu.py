@@ -286,10 +286,11 @@ def test_batch_norm_relu(ops, C, dt, train):
     bn_dev = copy.deepcopy(bn_ref).to(DEV)
     bn_ref.train(train); bn_dev.train(train)
     yr = y.float().clone().requires_grad_(True)
-    ref = F.relu(bn_ref(yr))
+    pre = det_uniform((C,), "bn:pre", 0.7)                       # the convolution bias in front of the BN
+    ref = F.relu(bn_ref(yr + pre.view(1, C, 1, 1)))
     (ref * gout.float()).sum().backward()
     yd = y.to(DEV).contiguous(memory_format=torch.channels_last).requires_grad_(True)
-    out = ops.batch_norm_relu(yd, bn_dev, train)
+    out = ops.batch_norm_relu(yd, bn_dev, train, pre.to(DEV))
     assert out.dtype == dt and out.is_contiguous(memory_format=torch.channels_last)
     out.backward(gout.to(DEV).contiguous(memory_format=torch.channels_last))
     tol = dict(rtol=1e-4, atol=1e-5) if dt == torch.float32 else dict(rtol=2e-2, atol=2e-2)
