@@ -70,6 +70,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bucket-mb", type=float, default=32.0)
     ap.add_argument("--eager", action="store_true", help="do not capture the step into a HIP graph")
+    ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); 'gloo' lets two "
+                    "ranks rehearse the N > 1 code path on one GPU together with --device")
+    ap.add_argument("--device", type=int, default=None, help="force this HIP device index for every rank (rehearsal only)")
     ap.add_argument("--kernel-steps", type=int, default=3,
                     help="eager steps run after the timed region to time individual kernels with HIP events")
     args = ap.parse_args()
@@ -77,10 +80,10 @@ def main():
     from panoswintransformerobjectdetection_amd import SimplePanoSwinTransformer, _lib
     from panoswintransformerobjectdetection_amd.dp import GradReducer, init_distributed
 
-    rank, local_rank, world = init_distributed()
+    rank, local_rank, world = init_distributed(args.backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", local_rank if args.device is None else args.device)
     torch.cuda.set_device(dev)
     _lib.load()                                  # fail loudly if the HIP library is missing
 
