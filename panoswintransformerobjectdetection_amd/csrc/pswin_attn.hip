@@ -189,6 +189,36 @@ __device__ inline void store_quad(void* base, size_t off, f32x4 q) {
     store4<DT>(base, off, q);
 }
 
+__device__ inline void swap16_u32(unsigned& a, unsigned& b) { asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b)); }
+
+// A lane (c, g) holds, for one output row, the head-dim quads q0 = d[4g .. 4g+3] and q1 = d[16+4g .. 16+4g+3] (the two
+// 16-wide MFMA tiles).  Exchanging q1 of the even groups with q0 of the odd groups (lanes 16 apart: one
+// v_permlane16_swap per dword) leaves every lane with 8 CONTIGUOUS elements, d0 = 8 (g >> 1) + 16 (g & 1), so the row
+// is written with half as many, twice as wide stores (8-byte bf16 stores are store-issue bound: MI355X guide T21).
+// base == nullptr: take part in the exchange (every lane must), skip the store (padded rows >= 49).
+template <int DT>
+__device__ inline void store_row8_guard(void* base, size_t row_off, int g, f32x4 q0, f32x4 q1) {
+    const int d0 = 8 * (g >> 1) + 16 * (g & 1);
+    if constexpr (DT == PSWIN_BF16) {
+        unsigned a0 = (unsigned)f32_to_bf16_bits(q0[0]) | ((unsigned)f32_to_bf16_bits(q0[1]) << 16);
+        unsigned a1 = (unsigned)f32_to_bf16_bits(q0[2]) | ((unsigned)f32_to_bf16_bits(q0[3]) << 16);
+        unsigned b0 = (unsigned)f32_to_bf16_bits(q1[0]) | ((unsigned)f32_to_bf16_bits(q1[1]) << 16);
+        unsigned b1 = (unsigned)f32_to_bf16_bits(q1[2]) | ((unsigned)f32_to_bf16_bits(q1[3]) << 16);
+        swap16_u32(a0, b0);
+        swap16_u32(a1, b1);
+        const u32x4 v = {a0, a1, b0, b1};
+        if (base) *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(base) + row_off + d0) = v;
+    } else {
+        // f32 quads are already 16-byte stores: no exchange needed
+        (void)d0;
+        if (base) {
+            float* p = reinterpret_cast<float*>(base) + row_off;
+            *reinterpret_cast<f32x4*>(p + 4 * g) = q0;
+            *reinterpret_cast<f32x4*>(p + 16 + 4 * g) = q1;
+        }
+    }
+}
+
 // Cross-lane reductions on the VALU (no ds_bpermute round trips through the LDS crossbar).
 // v_permlane16_swap(a, b) exchanges the odd 16-lane rows of a with the even rows of b; with a = b = v the two results
 // are [r0 r0 r2 r2] and [r1 r1 r3 r3], so combining them reduces over lane ^ 16.  v_permlane32_swap likewise for ^ 32.
@@ -297,51 +327,68 @@ struct Tiles4 {
 // ---------------------------------------------------------------------------------------------
 // forward
 // ---------------------------------------------------------------------------------------------
-template <int DT, int WAVES>
-__global__ __launch_bounds__(64 * WAVES, (DT == PSWIN_BF16 ? 2 : 1)) void attn_fwd_kernel(AttnArgs a) {   // bf16: <= 256 VGPRs
+// NQ = query tiles (of 16) per work item: 4 = the whole window, 2 = half of its queries (query rows are independent
+// in the forward pass, so a window-head splits into two work items that both read all of K and V: half the bias /
+// score registers per wave -> 3 waves per SIMD instead of 2, twice the items for load balance; K/V are re-read from L2).
+template <int DT, int NQ>
+struct FwdTiles {
+    Frag<DT> q[NQ], k[4], v[4];
+};
+
+template <int DT, int WAVES, int NQ>
+__global__ __launch_bounds__(64 * WAVES, (DT == PSWIN_BF16 ? (NQ == 2 ? 3 : 2) : 1)) void attn_fwd_kernel(AttnArgs a) {
     using VImg = LdsImg<DT, HD>;
     constexpr int WBYTES = VImg::BYTES + 2 * TABP * 4;
+    constexpr int NSPLIT = 4 / NQ;
     __shared__ __attribute__((aligned(16))) char smem[WAVES * WBYTES];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c = lane & 15, g = lane >> 4;
     const int item = blockIdx.x * WAVES + wave;
     if (item >= a.n_items) return;   // wave-uniform
-    const int h = item % a.heads;
-    const int wb = (item / a.heads) % a.nb;
-    const int chunk = item / (a.heads * a.nb);
+    const int qs = item % NSPLIT;    // which part of the queries
+    const int rest = item / NSPLIT;
+    const int h = rest % a.heads;
+    const int wb = (rest / a.heads) % a.nb;
+    const int chunk = rest / (a.heads * a.nb);
+    const int ti0 = qs * NQ;
     char* vimg = smem + wave * WBYTES;
     float* tab_a = reinterpret_cast<float*>(vimg + VImg::BYTES);
     float* tab_b = tab_a + TABP;
 
-    auto load_tiles = [&](int r, Tiles3<DT>& t) {
+    auto load_tiles = [&](int r, FwdTiles<DT, NQ>& t) {
         const size_t row0 = ((size_t)(chunk * a.reps_per_chunk + r) * a.nb + wb) * TOK;
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
             const int row = 16 * tt + c;
             const bool ok = row < TOK;
             const size_t off = (row0 + row) * (size_t)a.ld_qkv + h * HD + 8 * g;
-            t.q[tt] = load_frag<DT>(a.q, off, ok);
             t.k[tt] = load_frag<DT>(a.k, off, ok);
             t.v[tt] = load_frag<DT>(a.v, off, ok);
         }
+#pragma unroll
+        for (int tq = 0; tq < NQ; ++tq) {
+            const int row = 16 * (ti0 + tq) + c;
+            t.q[tq] = load_frag<DT>(a.q, (row0 + row) * (size_t)a.ld_qkv + h * HD + 8 * g, row < TOK);
+        }
     };
-    Tiles3<DT> cur;
+    FwdTiles<DT, NQ> cur;
     load_tiles(0, cur);              // in flight while the bias is being built
 
     load_tables(a, h, lane, tab_a, tab_b);
     __builtin_amdgcn_wave_barrier();
     const float inv_scale = 1.0f / a.scale;
     const float sl2e = a.scale * LOG2E;          // scores are kept unscaled: p = exp2((s' - m') * scale * log2 e)
-    // bias tile of (wb, h) / scale: query on the lane, 4 consecutive keys per quad; in VGPRs for the whole batch loop
-    f32x4 bias[4][4];
+    // bias of (wb, h) / scale for this item's queries: query on the lane, 4 consecutive keys per quad; in VGPRs for
+    // the whole batch loop
+    f32x4 bias[NQ][4];
     {
         const float* dtile = a.dist ? a.dist + (size_t)(wb % a.n_dist) * (PADT * PADT) : nullptr;
         const float* mtile = a.mask ? a.mask + (size_t)(wb % a.n_mask) * (PADT * PADT) : nullptr;
 #pragma unroll
-        for (int ti = 0; ti < 4; ++ti)
+        for (int tq = 0; tq < NQ; ++tq)
 #pragma unroll
             for (int tj = 0; tj < 4; ++tj)
-                bias[ti][tj] = bias_quad<false>(dtile, mtile, tab_a, tab_b, 16 * ti + c, 16 * tj + 4 * g, inv_scale);
+                bias[tq][tj] = bias_quad<false>(dtile, mtile, tab_a, tab_b, 16 * (ti0 + tq) + c, 16 * tj + 4 * g, inv_scale);
     }
 
     for (int r = 0; r < a.reps_per_chunk; ++r) {
@@ -349,12 +396,12 @@ __global__ __launch_bounds__(64 * WAVES, (DT == PSWIN_BF16 ? 2 : 1)) void attn_f
         const size_t row0 = win * TOK;
 #pragma unroll
         for (int t = 0; t < 4; ++t) lds_write_frag<DT, HD>(vimg, 16 * t + c, 8 * g, cur.v[t]);   // rows >= 49: zeros
-        // S^T tiles: keys 16 tj + 4 g + e on the accumulator rows, query 16 ti + c on the lane
-        f32x4 s4[4][4];
+        // S^T tiles: keys 16 tj + 4 g + e on the accumulator rows, query 16 (ti0 + tq) + c on the lane
+        f32x4 s4[NQ][4];
 #pragma unroll
-        for (int ti = 0; ti < 4; ++ti)
+        for (int tq = 0; tq < NQ; ++tq)
 #pragma unroll
-            for (int tj = 0; tj < 4; ++tj) s4[ti][tj] = mma32<DT>(cur.k[tj], cur.q[ti], bias[ti][tj]);
+            for (int tj = 0; tj < 4; ++tj) s4[tq][tj] = mma32<DT>(cur.k[tj], cur.q[tq], bias[tq][tj]);
         // the operand registers are free: request the next image now, its latency hides under softmax + PV
         if (r + 1 < a.reps_per_chunk) load_tiles(r + 1, cur);
         // V^T operand fragments: [k-step s][d tile dt]
@@ -364,61 +411,58 @@ __global__ __launch_bounds__(64 * WAVES, (DT == PSWIN_BF16 ? 2 : 1)) void attn_f
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) vt[s][dt] = lds_read_tr<DT, HD>(vimg, 32 * s + 4 * g, 16 * dt, c, g);
 
-        // softmax in phases over the 4 query tiles, so that the 4 independent cross-lane chains overlap
-        float m[4], l[4];
+        // softmax in phases over the query tiles, so that the independent cross-lane chains overlap
+        float m[NQ], l[NQ];
 #pragma unroll
-        for (int ti = 0; ti < 4; ++ti) {
-            float mm = s4[ti][3][0];                 // key tile 3 holds only key 48 (element 0 of group 0): rest is -inf
+        for (int tq = 0; tq < NQ; ++tq) {
+            float mm = s4[tq][3][0];                 // key tile 3 holds only key 48 (element 0 of group 0): rest is -inf
 #pragma unroll
             for (int tj = 0; tj < 3; ++tj)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) mm = fmaxf(mm, s4[ti][tj][e]);
-            m[ti] = mm;
+                for (int e = 0; e < 4; ++e) mm = fmaxf(mm, s4[tq][tj][e]);
+            m[tq] = mm;
         }
 #pragma unroll
-        for (int ti = 0; ti < 4; ++ti) m[ti] = group_max(m[ti]);
+        for (int tq = 0; tq < NQ; ++tq) m[tq] = group_max(m[tq]);
 #pragma unroll
-        for (int ti = 0; ti < 4; ++ti) {
-            const float mb = -m[ti] * sl2e;
+        for (int tq = 0; tq < NQ; ++tq) {
+            const float mb = -m[tq] * sl2e;
             float ll = 0.f;
 #pragma unroll
             for (int tj = 0; tj < 4; ++tj)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     if (tj == 3 && e > 0) {
-                        s4[ti][tj][e] = 0.f;         // keys 49..63: bias -inf, weight exactly 0
+                        s4[tq][tj][e] = 0.f;         // keys 49..63: bias -inf, weight exactly 0
                     } else {
-                        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s4[ti][tj][e], sl2e, mb));
-                        s4[ti][tj][e] = p;
+                        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(s4[tq][tj][e], sl2e, mb));
+                        s4[tq][tj][e] = p;
                         ll += p;
                     }
                 }
-            l[ti] = ll;
+            l[tq] = ll;
         }
 #pragma unroll
-        for (int ti = 0; ti < 4; ++ti) l[ti] = group_sum(l[ti]);
+        for (int tq = 0; tq < NQ; ++tq) l[tq] = group_sum(l[tq]);
         // O^T[d][i] = sum_j V^T[d][j] P^T[j][i]
-        f32x4 o[4][2];
 #pragma unroll
-        for (int ti = 0; ti < 4; ++ti) {
-            o[ti][0] = o[ti][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int tq = 0; tq < NQ; ++tq) {
+            f32x4 o[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                const Frag<DT> pf = pack_frag<DT>(s4[ti][2 * s], s4[ti][2 * s + 1]);
+                const Frag<DT> pf = pack_frag<DT>(s4[tq][2 * s], s4[tq][2 * s + 1]);
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt) o[ti][dt] = mma32<DT>(vt[s][dt], pf, o[ti][dt]);
+                for (int dt = 0; dt < 2; ++dt) o[dt] = mma32<DT>(vt[s][dt], pf, o[dt]);
             }
-        }
-#pragma unroll
-        for (int ti = 0; ti < 4; ++ti) {
-            const int i = 16 * ti + c;
-            const float inv_l = 1.0f / l[ti];
-            if (i < TOK) {
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
-                    store_quad<DT>(a.out, (row0 + i) * (size_t)a.ld_out + h * HD + 16 * dt + 4 * g, o[ti][dt] * inv_l);
+            const int i = 16 * (ti0 + tq) + c;
+            const float inv_l = 1.0f / l[tq];
+            // (the lane exchange inside store_row8 needs all lanes: rows >= 49 only skip the store itself)
+            {
+                const f32x4 o0 = o[0] * inv_l, o1 = o[1] * inv_l;
+                void* dst = (i < TOK) ? a.out : nullptr;
+                store_row8_guard<DT>(dst, (row0 + i) * (size_t)a.ld_out + h * HD, g, o0, o1);
             }
-            if (g == 0) a.lse[(win * a.heads + h) * PADT + i] = (i < TOK) ? __builtin_fmaf(m[ti], a.scale, logf(l[ti])) : INFINITY;
+            if (g == 0) a.lse[(win * a.heads + h) * PADT + i] = (i < TOK) ? __builtin_fmaf(m[tq], a.scale, logf(l[tq])) : INFINITY;
         }
     }
 }
@@ -570,14 +614,9 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_kernel(AttnArgs a) {
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj) {
             const int j = 16 * tj + c;
-            if (j < TOK) {
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    const size_t off = (row0 + j) * (size_t)a.ld_dqkv + h * HD + 16 * dt + 4 * g;
-                    store_quad<DT>(a.dv, off, dv[dt][tj]);
-                    store_quad<DT>(a.dk, off, dk[dt][tj] * a.scale);
-                }
-            }
+            const size_t off = (row0 + j) * (size_t)a.ld_dqkv + h * HD;
+            store_row8_guard<DT>(j < TOK ? a.dv : nullptr, off, g, dv[0][tj], dv[1][tj]);
+            store_row8_guard<DT>(j < TOK ? a.dk : nullptr, off, g, dk[0][tj] * a.scale, dk[1][tj] * a.scale);
         }
         // dQ^T[d][i] = scale * sum_j K^T[d][j] dS^T[j][i]
         f32x4 dq[2][4];
@@ -600,12 +639,8 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_kernel(AttnArgs a) {
 #pragma unroll
         for (int ti = 0; ti < 4; ++ti) {
             const int i = 16 * ti + c;
-            if (i < TOK) {
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
-                    store_quad<DT>(a.dq, (row0 + i) * (size_t)a.ld_dqkv + h * HD + 16 * dt + 4 * g,
-                                   dq[dt][ti] * a.scale);
-            }
+            store_row8_guard<DT>(i < TOK ? a.dq : nullptr, (row0 + i) * (size_t)a.ld_dqkv + h * HD, g,
+                                 dq[0][ti] * a.scale, dq[1][ti] * a.scale);
         }
         if constexpr (DUAL) {
             if (r + 1 < a.reps_per_chunk) cur = nxt;
@@ -758,15 +793,17 @@ extern "C" int pswin_attn_fwd(const void* q, const void* k, const void* v, int l
     a.out = out; a.lse = lse;
     a.ld_qkv = ld_qkv; a.ld_out = ld_out;
     a.nb = n_bias_windows; a.heads = heads; a.reps_per_chunk = reps / chunks;
-    a.n_items = chunks * n_bias_windows * heads;
     a.scale = scale;
     constexpr int W = 4;
-    if (dtype == PSWIN_BF16)
-        hipLaunchKernelGGL((attn_fwd_kernel<PSWIN_BF16, W>), dim3((a.n_items + W - 1) / W), dim3(64 * W), 0,
+    if (dtype == PSWIN_BF16) {
+        a.n_items = chunks * n_bias_windows * heads * 2;         // two work items (query halves) per window-head
+        hipLaunchKernelGGL((attn_fwd_kernel<PSWIN_BF16, W, 2>), dim3((a.n_items + W - 1) / W), dim3(64 * W), 0,
                            (hipStream_t)stream, a);
-    else
-        hipLaunchKernelGGL((attn_fwd_kernel<PSWIN_F32, W>), dim3((a.n_items + W - 1) / W), dim3(64 * W), 0,
+    } else {
+        a.n_items = chunks * n_bias_windows * heads;
+        hipLaunchKernelGGL((attn_fwd_kernel<PSWIN_F32, W, 4>), dim3((a.n_items + W - 1) / W), dim3(64 * W), 0,
                            (hipStream_t)stream, a);
+    }
     PSWIN_LAUNCH_RET();
 }
 
