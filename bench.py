@@ -77,6 +77,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bucket-mb", type=float, default=32.0)
     ap.add_argument("--eager", action="store_true", help="do not capture the step into a HIP graph")
+    ap.add_argument("--model", default="T", choices=["T", "S"], help="PanoSwin-T (depths 2-2-6-2, the headline) or -S (2-2-18-2)")
+    ap.add_argument("--height", type=int, default=512, help="panorama height; width = 2 * height (headline: 512)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); 'gloo' lets two "
                     "ranks rehearse the N > 1 code path on one GPU together with --device")
     ap.add_argument("--device", type=int, default=None, help="force this HIP device index for every rank (rehearsal only)")
@@ -96,7 +98,8 @@ def main():
 
     torch.manual_seed(0)
     cd = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    model = SimplePanoSwinTransformer(**TCFG, compute_dtype=cd)
+    cfg = dict(TCFG, depths=[2, 2, 18, 2]) if args.model == "S" else TCFG
+    model = SimplePanoSwinTransformer(**cfg, compute_dtype=cd)
     model.init_weights(None)
     model = model.to(dev).train()
     reducer = GradReducer(model, bucket_mb=args.bucket_mb, pack=not args.eager)
@@ -105,7 +108,7 @@ def main():
                             capturable=not args.eager)
 
     torch.manual_seed(1234 + rank)               # every rank its own shard of synthetic panoramas
-    x = torch.randn(args.batch, 3, 512, 1024, device=dev)
+    x = torch.randn(args.batch, 3, args.height, 2 * args.height, device=dev)
 
     def fwd_bwd():
         reducer.zero_grad()
@@ -200,11 +203,12 @@ def main():
                     "algorithmic_bytes_per_launch": round(algo_per_launch),
                     "avg_launch_us": stats[dom]["avg_us"], "kernels": stats}
         line = {
-            "metric": "panoramas/sec PanoSwin-T 512x1024 fwd+bwd", "value": round(value, 2), "unit": "panoramas/s",
+            "metric": f"panoramas/sec PanoSwin-{args.model} {args.height}x{2 * args.height} fwd+bwd", "value": round(value, 2), "unit": "panoramas/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "PanoSwin-T backbone (embed 96, depths 2-2-6-2, heads 3-6-12-24, ape, pano mode) "
-                                   "fwd+bwd+AdamW on 3x512x1024 panoramas, BASELINE.json configs[1]",
+            "config": {"workload": (f"PanoSwin-{args.model} backbone (embed 96, depths {'-'.join(map(str, cfg['depths']))}, "
+                                    f"heads 3-6-12-24, ape, pano mode) fwd+bwd+AdamW on 3x{args.height}x{2 * args.height} "
+                                    "panoramas" + (", BASELINE.json configs[1]" if (args.model, args.height) == ("T", 512) else "")),
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "grad_bucket_mb": args.bucket_mb, "hip_graph": not args.eager,
                        "device": torch.cuda.get_device_name(dev)},
