@@ -659,6 +659,224 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_kernel(AttnArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// backward, two waves per (window, head) work item (bf16)
+// ---------------------------------------------------------------------------------------------
+// The single-wave backward above needs ~450 registers (bias 64 + dS-sum 64 + dV/dK accumulators 64 + operands 64 + P/dS
+// 64 + ...), i.e. one wave per SIMD: every LDS round trip, MFMA result latency and memory wait is exposed (measured
+// ~19 cycles per instruction).  Here a workgroup = 2 waves = one work item, split by QUERY halves (wave w owns query
+// tiles 2w, 2w+1): bias, dS-sum, P and dS are halved, delta and dQ are complete per wave (they contract over keys, and
+// each wave sees all keys); only dV / dK contract over queries, so each wave holds a partial over its 32 queries and
+// the two exchange ONE partial each through LDS (wave 0 finishes dV, wave 1 finishes dK).  ~200 registers -> two waves
+// per SIMD.  K and V are loaded by both waves (second read hits L2).
+struct PairLds {
+    static constexpr int KIMG = 64 * 32 * 2;        // K image [64 keys][32] bf16 (shared: transposed reads for dQ)
+    static constexpr int HALF = 32 * 32 * 2;        // per wave: Q / dO images of its 32 query rows
+    static constexpr int TIMG = 64 * 32 * 2;        // per wave: dS^T [64 keys][32 own queries]
+    static constexpr int EXCH = 64 * 32 * 4;        // one f32 partial [64 keys][32 d]
+    static constexpr int TAB = 2 * TABP * 4;
+    static constexpr int BYTES = KIMG + 2 * (2 * HALF + TIMG) + 2 * EXCH + TAB;
+};
+
+// transposed read of a 32-column bf16 image with 32-row operand blocks (rows R0+{0..3}, R0+16+{0..3})
+__device__ inline Frag<PSWIN_BF16> tr32(const char* img, int ld_elems, int R0, int col0, int c) {
+    const int q = c >> 2, p = c & 3;
+    typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+    const char* a0 = img + ((size_t)(R0 + q) * ld_elems + col0 + 4 * p) * 2;
+    const char* a1 = a0 + (size_t)16 * ld_elems * 2;
+    s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a0));
+    s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a1));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    Frag<PSWIN_BF16> f;
+    f.v = __builtin_bit_cast(bf16x8, both);
+    return f;
+}
+
+__global__ __launch_bounds__(128, 2) void attn_bwd_pair_kernel(AttnArgs a) {
+    constexpr int DT = PSWIN_BF16;
+    __shared__ __attribute__((aligned(16))) char smem[PairLds::BYTES];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;      // w = query half
+    const int c = lane & 15, g = lane >> 4;
+    const int item = blockIdx.x;
+    const int h = item % a.heads;
+    const int wb = (item / a.heads) % a.nb;
+    const int chunk = item / (a.heads * a.nb);
+    char* kimg = smem;
+    char* qimg = kimg + PairLds::KIMG + w * (2 * PairLds::HALF + PairLds::TIMG);
+    char* doimg = qimg + PairLds::HALF;
+    char* timg = doimg + PairLds::HALF;
+    float* exch_dk = reinterpret_cast<float*>(smem + PairLds::KIMG + 2 * (2 * PairLds::HALF + PairLds::TIMG));   // from wave 0
+    float* exch_dv = exch_dk + 64 * 32;                                                                        // from wave 1
+    float* tab_a = exch_dv + 64 * 32;
+    float* tab_b = tab_a + TABP;
+    const float* dtile = a.dist ? a.dist + (size_t)(wb % a.n_dist) * (PADT * PADT) : nullptr;   // transposed: [j][i]
+    const float* mtile = a.mask ? a.mask + (size_t)(wb % a.n_mask) * (PADT * PADT) : nullptr;
+
+    struct Ops {
+        Frag<DT> q[2], d[2], k[4], v[4];
+    };
+    auto load_ops = [&](int r, Ops& t) {
+        const size_t row0 = ((size_t)(chunk * a.reps_per_chunk + r) * a.nb + wb) * TOK;
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+            const int row = 16 * tt + c;
+            const size_t off = (row0 + row) * (size_t)a.ld_qkv + h * HD + 8 * g;
+            t.k[tt] = load_frag<DT>(a.k, off, row < TOK);
+            t.v[tt] = load_frag<DT>(a.v, off, row < TOK);
+        }
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int row = 16 * (2 * w + tt) + c;
+            t.q[tt] = load_frag<DT>(a.q, (row0 + row) * (size_t)a.ld_qkv + h * HD + 8 * g, row < TOK);
+            t.d[tt] = load_frag<DT>(a.dout, (row0 + row) * (size_t)a.ld_out + h * HD + 8 * g, row < TOK);
+        }
+    };
+    Ops cur;
+    load_ops(0, cur);                 // in flight while the bias is being built
+
+    if (w == 0) load_tables(a, h, lane, tab_a, tab_b);
+    __syncthreads();
+    const float inv_scale = 1.0f / a.scale;
+    const float sl2e = a.scale * LOG2E;
+    // bias / scale for this wave's query tiles: rows i = 16 (2w + tt) + 4 g + e on the registers, key j = 16 tj + c
+    f32x4 bias[2][4], gsum[2][4];
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) {
+            bias[tt][tj] = bias_quad<true>(dtile, mtile, tab_a, tab_b, 16 * (2 * w + tt) + 4 * g, 16 * tj + c, inv_scale);
+            gsum[tt][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+
+    for (int r = 0; r < a.reps_per_chunk; ++r) {
+        const size_t win = (size_t)(chunk * a.reps_per_chunk + r) * a.nb + wb;
+        const size_t row0 = win * TOK;
+        // LDS images for the transposed operand reads
+        if (w == 0) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) *reinterpret_cast<bf16x8*>(kimg + ((size_t)(16 * t + c) * 32 + 8 * g) * 2) = cur.k[t].v;
+        }
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            *reinterpret_cast<bf16x8*>(qimg + ((size_t)(16 * tt + c) * 32 + 8 * g) * 2) = cur.q[tt].v;
+            *reinterpret_cast<bf16x8*>(doimg + ((size_t)(16 * tt + c) * 32 + 8 * g) * 2) = cur.d[tt].v;
+        }
+        const float* lse_row = a.lse + (win * a.heads + h) * PADT;
+        Frag<DT> pf[4], dsf[4];
+        {
+            f32x4 p4[2][4], ds4[2][4];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const int ti = 2 * w + tt;
+                f32x4 lse4 = *reinterpret_cast<const f32x4*>(lse_row + 16 * ti + 4 * g);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) lse4[e] = -lse4[e] * LOG2E;
+                f32x4 delta = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int tj = 0; tj < 4; ++tj) {
+                    const f32x4 sc = mma32<DT>(cur.q[tt], cur.k[tj], bias[tt][tj]);                  // (S + bias) / scale
+                    const f32x4 dp = mma32<DT>(cur.d[tt], cur.v[tj], f32x4{0.f, 0.f, 0.f, 0.f});     // dP[i][j]
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float p = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[e], sl2e, lse4[e]));   // rows >= 49: lse = +inf -> 0
+                        p4[tt][tj][e] = p;
+                        delta[e] = __builtin_fmaf(p, dp[e], delta[e]);
+                    }
+                    ds4[tt][tj] = dp;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) delta[e] = row16_sum(delta[e]);
+#pragma unroll
+                for (int tj = 0; tj < 4; ++tj) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ds4[tt][tj][e] = p4[tt][tj][e] * (ds4[tt][tj][e] - delta[e]);
+                    gsum[tt][tj] = gsum[tt][tj] + ds4[tt][tj];
+                    // dS^T[j][local i .. +3], local i = 16 tt + 4 g
+                    const bf16x4 b = {(__bf16)ds4[tt][tj][0], (__bf16)ds4[tt][tj][1], (__bf16)ds4[tt][tj][2], (__bf16)ds4[tt][tj][3]};
+                    *reinterpret_cast<bf16x4*>(timg + ((size_t)(16 * tj + c) * 32 + 16 * tt + 4 * g) * 2) = b;
+                }
+            }
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj) {
+                pf[tj] = pack_frag<DT>(p4[0][tj], p4[1][tj]);
+                dsf[tj] = pack_frag<DT>(ds4[0][tj], ds4[1][tj]);
+            }
+        }
+        // operands consumed: request the next image
+        if (r + 1 < a.reps_per_chunk) load_ops(r + 1, cur);
+
+        // partial dV^T / dK^T over this wave's 32 queries: [dt][tj], rows d = 16 dt + 4 g + e, column key j = 16 tj + c.
+        // wave 0 keeps dV and sends dK, wave 1 keeps dK and sends dV
+        Frag<DT> dot[2], qt[2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            dot[dt] = tr32(doimg, 32, 4 * g, 16 * dt, c);
+            qt[dt] = tr32(qimg, 32, 4 * g, 16 * dt, c);
+        }
+        f32x4 keep[2][4];
+        {
+            float* exch = w == 0 ? exch_dk : exch_dv;
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    const f32x4 dvp = mma32<DT>(dot[dt], pf[tj], z);
+                    const f32x4 dkp = mma32<DT>(qt[dt], dsf[tj], z);
+                    keep[dt][tj] = w == 0 ? dvp : dkp;
+                    *reinterpret_cast<f32x4*>(exch + (16 * tj + c) * 32 + 16 * dt + 4 * g) = w == 0 ? dkp : dvp;
+                }
+        }
+        __syncthreads();          // exchange written, K image written
+        {
+            const float* other = w == 0 ? exch_dv : exch_dk;
+            void* dst = w == 0 ? a.dv : a.dk;
+            const float mul = w == 0 ? 1.0f : a.scale;
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj) {
+                const int j = 16 * tj + c;
+                const f32x4 o0 = (keep[0][tj] + *reinterpret_cast<const f32x4*>(other + j * 32 + 4 * g)) * mul;
+                const f32x4 o1 = (keep[1][tj] + *reinterpret_cast<const f32x4*>(other + j * 32 + 16 + 4 * g)) * mul;
+                store_row8_guard<DT>(j < TOK ? dst : nullptr, (row0 + j) * (size_t)a.ld_dqkv + h * HD, g, o0, o1);
+            }
+        }
+        // dQ^T[d][i] = scale * sum_j K^T[d][j] dS^T[j][i] for this wave's queries
+        f32x4 dq[2][2];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) dq[dt][tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            Frag<DT> kt[2];
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) kt[dt] = tr32(kimg, 32, 32 * s + 4 * g, 16 * dt, c);
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const Frag<DT> tf = tr32(timg, 32, 32 * s + 4 * g, 16 * tt, c);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) dq[dt][tt] = mma32<DT>(kt[dt], tf, dq[dt][tt]);
+            }
+        }
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int i = 16 * (2 * w + tt) + c;
+            store_row8_guard<DT>(i < TOK ? a.dq : nullptr, (row0 + i) * (size_t)a.ld_dqkv + h * HD, g, dq[0][tt] * a.scale,
+                                 dq[1][tt] * a.scale);
+        }
+        __syncthreads();          // both waves are done with the K image and the exchange buffers
+    }
+    if (a.dtab) {
+        float* gt = a.dtab + (size_t)item * (PADT * PADT);
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj)
+                *reinterpret_cast<f32x4*>(gt + (16 * tj + c) * PADT + 16 * (2 * w + tt) + 4 * g) = gsum[tt][tj];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // helpers around the main kernels
 // ---------------------------------------------------------------------------------------------
 // [n][49][49] -> [n][64][64], optionally transposed, zero padded: the tile layout the attention kernels read
@@ -840,9 +1058,7 @@ extern "C" int pswin_attn_bwd(const void* q, const void* k, const void* v, int l
     a.n_items = n_chunks * n_bias_windows * heads;
     a.scale = scale;
     if (dtype == PSWIN_BF16) {
-        constexpr int W = 4;
-        hipLaunchKernelGGL((attn_bwd_kernel<PSWIN_BF16, W>), dim3((a.n_items + W - 1) / W), dim3(64 * W), 0,
-                           (hipStream_t)stream, a);
+        hipLaunchKernelGGL(attn_bwd_pair_kernel, dim3(a.n_items), dim3(128), 0, (hipStream_t)stream, a);
     } else {
         constexpr int W = 3;
         hipLaunchKernelGGL((attn_bwd_kernel<PSWIN_F32, W>), dim3((a.n_items + W - 1) / W), dim3(64 * W), 0,
