@@ -89,6 +89,48 @@ __device__ inline Frag<DT> load_frag(const void* base, size_t off, bool valid) {
     return f;
 }
 
+// Operand addressing: buffer instructions.  Per image a wave builds one buffer resource per tensor on the SALU (base
+// = row 0 of the window, column 0 of the head; range = rows 0..48 of that head), and every lane keeps ONE loop-invariant
+// 32-bit byte offset per access slot: `buffer_load_dwordx4 v, v_off, s[rsrc], 0 offen`.  Against flat 64-bit VGPR
+// addresses this (a) frees ~2 VGPRs per slot and the VALU adds that rebuilt them per image (the backward kernel was
+// spilling its pointers; the reloads serialised on vmcnt(0) behind the prefetch of the next image), and (b) makes the
+// padded rows 49..63 free: their offsets fall outside the resource's range, so loads return zeros and stores are
+// dropped by the hardware range check -- no branches, no exec masking.
+template <int DT>
+constexpr int ES = (DT == PSWIN_BF16) ? 2 : 4;
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+
+// resource for the [49 rows][HD] head slice starting at base + byte_off, rows ld elements apart
+template <int DT>
+__device__ inline rsrc_t window_rsrc(const void* base, size_t byte_off, int ld) {
+    char* p = const_cast<char*>(reinterpret_cast<const char*>(base)) + byte_off;
+    return __builtin_amdgcn_make_buffer_rsrc(p, 0, ((TOK - 1) * ld + HD) * ES<DT>, 0x00020000);
+}
+
+// byte offset of the 8-element group g of row `row` within the window's head slice
+template <int DT>
+__device__ inline unsigned row_off(int row, int ld, int g) {
+    return (unsigned)(row * ld + 8 * g) * ES<DT>;
+}
+
+template <int DT>
+__device__ inline Frag<DT> load_frag_at(rsrc_t rs, unsigned boff) {
+    Frag<DT> f;
+    if constexpr (DT == PSWIN_BF16) {
+        u32x4 raw = __builtin_amdgcn_raw_buffer_load_b128(rs, boff, 0, 0);
+        f.v = __builtin_bit_cast(bf16x8, raw);
+    } else {
+        const f32x4 a = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, boff, 0, 0));
+        const f32x4 b = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, boff + 16u, 0, 0));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            f.v[i] = a[i];
+            f.v[4 + i] = b[i];
+        }
+    }
+    return f;
+}
+
 // two accumulator quads -> the 8-element operand of the next MFMA (k order: lo[0..3], hi[0..3])
 template <int DT>
 __device__ inline Frag<DT> pack_frag(f32x4 lo, f32x4 hi) {
@@ -126,16 +168,26 @@ __device__ inline f32x4 mma32(const Frag<DT>& a, const Frag<DT>& b, f32x4 acc) {
 // ---------------------------------------------------------------------------------------------
 template <int DT, int COLS>
 struct LdsImg {
-    // row stride in elements: bf16 rows stay dense (tr reads need 8-byte aligned, rows multiple of 8 B);
-    // f32 rows get 4 floats of padding so that the 4 lane groups of a column read hit different banks.
-    static constexpr int LD = (DT == PSWIN_BF16) ? COLS : COLS + 4;
+    // bf16 [.][32] images: dense 64-byte rows whose four 16-byte chunks are XOR-swizzled by the row (img32_off below);
+    // other bf16 images: 16 bytes of row padding; f32 rows: 4 floats of padding so that the 4 lane groups of a column
+    // read hit different banks.
+    static constexpr int LD = (DT == PSWIN_BF16) ? (COLS == 32 ? 32 : COLS + 8) : COLS + 4;
     static constexpr int BYTES = PADT * LD * (DT == PSWIN_BF16 ? 2 : 4);
 };
+
+// Byte offset of 16-byte chunk `chunk16` (0..3) of row `row` in a bf16 [.][32] image.  Dense power-of-two rows are the
+// worst case for the LDS banks (SQ_LDS_BANK_CONFLICT measured 5x the conflict-free LDS time in the backward kernel):
+// a ds_write_b128 of 8 rows hits 2 bank groups (4-way), a ds_read_b64_tr_b16 half-wave (8 rows x 32 B) 2-way.  XOR-ing
+// the chunk with bits 1..2 of the row makes both conflict-free: rows of equal parity get 4 different chunks, and rows
+// r, r + 4 (same quarter of the 64 banks) use different 32-byte halves.  Unchanged by row + 16.
+__device__ inline int img32_off(int row, int chunk16) { return row * 64 + ((chunk16 ^ ((row >> 1) & 3)) << 4); }
 
 template <int DT, int COLS>
 __device__ inline void lds_write_frag(char* img, int row, int col, const Frag<DT>& f) {
     constexpr int LD = LdsImg<DT, COLS>::LD;
-    if constexpr (DT == PSWIN_BF16) {
+    if constexpr (DT == PSWIN_BF16 && COLS == 32) {
+        *reinterpret_cast<bf16x8*>(img + img32_off(row, col >> 3)) = f.v;
+    } else if constexpr (DT == PSWIN_BF16) {
         *reinterpret_cast<bf16x8*>(img + ((size_t)row * LD + col) * 2) = f.v;
     } else {
         float* p = reinterpret_cast<float*>(img) + (size_t)row * LD + col;
@@ -167,7 +219,13 @@ __device__ inline Frag<DT> lds_read_tr(const char* img, int R0, int col0, int c,
         // column (4q+p) of the 4 rows.
         const int q = c >> 2, p = c & 3;
         typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
-        const char* a0 = img + ((size_t)(R0 + q) * LD + col0 + 4 * p) * 2;
+        const char* a0;
+        if constexpr (COLS == 32) {
+            const int k8 = (col0 >> 2) + p;               // 8-byte unit within the row
+            a0 = img + img32_off(R0 + q, k8 >> 1) + ((k8 & 1) << 3);
+        } else {
+            a0 = img + ((size_t)(R0 + q) * LD + col0 + 4 * p) * 2;
+        }
         const char* a1 = a0 + (size_t)16 * LD * 2;
         s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a0));
         s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a1));
@@ -195,9 +253,10 @@ __device__ inline void swap16_u32(unsigned& a, unsigned& b) { asm volatile("s_no
 // 16-wide MFMA tiles).  Exchanging q1 of the even groups with q0 of the odd groups (lanes 16 apart: one
 // v_permlane16_swap per dword) leaves every lane with 8 CONTIGUOUS elements, d0 = 8 (g >> 1) + 16 (g & 1), so the row
 // is written with half as many, twice as wide stores (8-byte bf16 stores are store-issue bound: MI355X guide T21).
-// base == nullptr: take part in the exchange (every lane must), skip the store (padded rows >= 49).
+// Every lane takes part in the exchange; the stores of padded rows (>= 49) are dropped by the buffer range check.
+// row_boff: byte offset of the lane's row within the window's head slice (see window_rsrc).
 template <int DT>
-__device__ inline void store_row8_guard(void* base, size_t row_off, int g, f32x4 q0, f32x4 q1) {
+__device__ inline void store_row8_at(rsrc_t rs, unsigned row_boff, int g, f32x4 q0, f32x4 q1) {
     const int d0 = 8 * (g >> 1) + 16 * (g & 1);
     if constexpr (DT == PSWIN_BF16) {
         unsigned a0 = (unsigned)f32_to_bf16_bits(q0[0]) | ((unsigned)f32_to_bf16_bits(q0[1]) << 16);
@@ -207,15 +266,12 @@ __device__ inline void store_row8_guard(void* base, size_t row_off, int g, f32x4
         swap16_u32(a0, b0);
         swap16_u32(a1, b1);
         const u32x4 v = {a0, a1, b0, b1};
-        if (base) *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(base) + row_off + d0) = v;
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, row_boff + (unsigned)d0 * 2u, 0, 0);
     } else {
         // f32 quads are already 16-byte stores: no exchange needed
         (void)d0;
-        if (base) {
-            float* p = reinterpret_cast<float*>(base) + row_off;
-            *reinterpret_cast<f32x4*>(p + 4 * g) = q0;
-            *reinterpret_cast<f32x4*>(p + 16 + 4 * g) = q1;
-        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q0), rs, row_boff + 16u * g, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q1), rs, row_boff + 64u + 16u * g, 0, 0);
     }
 }
 
@@ -341,7 +397,7 @@ __global__ __launch_bounds__(64 * WAVES, (DT == PSWIN_BF16 ? (NQ == 2 ? 3 : 2) :
     constexpr int WBYTES = VImg::BYTES + 2 * TABP * 4;
     constexpr int NSPLIT = 4 / NQ;
     __shared__ __attribute__((aligned(16))) char smem[WAVES * WBYTES];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;   // scalar item math
     const int c = lane & 15, g = lane >> 4;
     const int item = blockIdx.x * WAVES + wave;
     if (item >= a.n_items) return;   // wave-uniform
@@ -355,21 +411,27 @@ __global__ __launch_bounds__(64 * WAVES, (DT == PSWIN_BF16 ? (NQ == 2 ? 3 : 2) :
     float* tab_a = reinterpret_cast<float*>(vimg + VImg::BYTES);
     float* tab_b = tab_a + TABP;
 
+    unsigned kv_off[4], q_off[NQ], o_off[NQ];          // per-lane byte offsets within a window, loop invariant
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) kv_off[tt] = row_off<DT>(16 * tt + c, a.ld_qkv, g);
+#pragma unroll
+    for (int tq = 0; tq < NQ; ++tq) {
+        q_off[tq] = row_off<DT>(16 * (ti0 + tq) + c, a.ld_qkv, g);
+        o_off[tq] = (unsigned)((16 * (ti0 + tq) + c) * a.ld_out) * ES<DT>;
+    }
     auto load_tiles = [&](int r, FwdTiles<DT, NQ>& t) {
         const size_t row0 = ((size_t)(chunk * a.reps_per_chunk + r) * a.nb + wb) * TOK;
+        const size_t head0 = (row0 * (size_t)a.ld_qkv + h * HD) * ES<DT>;
+        const rsrc_t qb = window_rsrc<DT>(a.q, head0, a.ld_qkv);
+        const rsrc_t kb = window_rsrc<DT>(a.k, head0, a.ld_qkv);
+        const rsrc_t vb = window_rsrc<DT>(a.v, head0, a.ld_qkv);
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
-            const int row = 16 * tt + c;
-            const bool ok = row < TOK;
-            const size_t off = (row0 + row) * (size_t)a.ld_qkv + h * HD + 8 * g;
-            t.k[tt] = load_frag<DT>(a.k, off, ok);
-            t.v[tt] = load_frag<DT>(a.v, off, ok);
+            t.k[tt] = load_frag_at<DT>(kb, kv_off[tt]);
+            t.v[tt] = load_frag_at<DT>(vb, kv_off[tt]);
         }
 #pragma unroll
-        for (int tq = 0; tq < NQ; ++tq) {
-            const int row = 16 * (ti0 + tq) + c;
-            t.q[tq] = load_frag<DT>(a.q, (row0 + row) * (size_t)a.ld_qkv + h * HD + 8 * g, row < TOK);
-        }
+        for (int tq = 0; tq < NQ; ++tq) t.q[tq] = load_frag_at<DT>(qb, q_off[tq]);
     };
     FwdTiles<DT, NQ> cur;
     load_tiles(0, cur);              // in flight while the bias is being built
@@ -394,6 +456,7 @@ __global__ __launch_bounds__(64 * WAVES, (DT == PSWIN_BF16 ? (NQ == 2 ? 3 : 2) :
     for (int r = 0; r < a.reps_per_chunk; ++r) {
         const size_t win = (size_t)(chunk * a.reps_per_chunk + r) * a.nb + wb;
         const size_t row0 = win * TOK;
+        const rsrc_t ob = window_rsrc<DT>(a.out, (row0 * (size_t)a.ld_out + h * HD) * ES<DT>, a.ld_out);
 #pragma unroll
         for (int t = 0; t < 4; ++t) lds_write_frag<DT, HD>(vimg, 16 * t + c, 8 * g, cur.v[t]);   // rows >= 49: zeros
         // S^T tiles: keys 16 tj + 4 g + e on the accumulator rows, query 16 (ti0 + tq) + c on the lane
@@ -459,10 +522,12 @@ __global__ __launch_bounds__(64 * WAVES, (DT == PSWIN_BF16 ? (NQ == 2 ? 3 : 2) :
             // (the lane exchange inside store_row8 needs all lanes: rows >= 49 only skip the store itself)
             {
                 const f32x4 o0 = o[0] * inv_l, o1 = o[1] * inv_l;
-                void* dst = (i < TOK) ? a.out : nullptr;
-                store_row8_guard<DT>(dst, (row0 + i) * (size_t)a.ld_out + h * HD, g, o0, o1);
+                store_row8_at<DT>(ob, o_off[tq], g, o0, o1);
             }
-            if (g == 0) a.lse[(win * a.heads + h) * PADT + i] = (i < TOK) ? __builtin_fmaf(m[tq], a.scale, logf(l[tq])) : INFINITY;
+            if (g == 0) {
+                float* lse_row = a.lse + (win * a.heads + h) * PADT;
+                lse_row[(unsigned)i] = (i < TOK) ? __builtin_fmaf(m[tq], a.scale, logf(l[tq])) : INFINITY;
+            }
         }
     }
 }
@@ -481,7 +546,7 @@ template <int DT, int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void attn_bwd_kernel(AttnArgs a) {
     using L = BwdLds<DT>;
     __shared__ __attribute__((aligned(16))) char smem[WAVES * L::BYTES];
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int c = lane & 15, g = lane >> 4;
     const int item = blockIdx.x * WAVES + wave;
     if (item >= a.n_items) return;   // wave-uniform
@@ -497,17 +562,26 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_kernel(AttnArgs a) {
     const float* dtile = a.dist ? a.dist + (size_t)(wb % a.n_dist) * (PADT * PADT) : nullptr;   // transposed: [j][i]
     const float* mtile = a.mask ? a.mask + (size_t)(wb % a.n_mask) * (PADT * PADT) : nullptr;
 
+    unsigned in_off[4], do_off[4], dx_off[4];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+        in_off[tt] = row_off<DT>(16 * tt + c, a.ld_qkv, g);
+        do_off[tt] = row_off<DT>(16 * tt + c, a.ld_out, g);
+        dx_off[tt] = (unsigned)((16 * tt + c) * a.ld_dqkv) * ES<DT>;
+    }
     auto load_tiles = [&](int r, Tiles4<DT>& t) {
         const size_t row0 = ((size_t)(chunk * a.reps_per_chunk + r) * a.nb + wb) * TOK;
+        const size_t head0 = (row0 * (size_t)a.ld_qkv + h * HD) * ES<DT>;
+        const rsrc_t qb = window_rsrc<DT>(a.q, head0, a.ld_qkv);
+        const rsrc_t kb = window_rsrc<DT>(a.k, head0, a.ld_qkv);
+        const rsrc_t vb = window_rsrc<DT>(a.v, head0, a.ld_qkv);
+        const rsrc_t db = window_rsrc<DT>(a.dout, (row0 * (size_t)a.ld_out + h * HD) * ES<DT>, a.ld_out);
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
-            const int row = 16 * tt + c;
-            const bool ok = row < TOK;
-            const size_t off = (row0 + row) * (size_t)a.ld_qkv + h * HD + 8 * g;
-            t.q[tt] = load_frag<DT>(a.q, off, ok);
-            t.k[tt] = load_frag<DT>(a.k, off, ok);
-            t.v[tt] = load_frag<DT>(a.v, off, ok);
-            t.d[tt] = load_frag<DT>(a.dout, (row0 + row) * (size_t)a.ld_out + h * HD + 8 * g, ok);
+            t.q[tt] = load_frag_at<DT>(qb, in_off[tt]);
+            t.k[tt] = load_frag_at<DT>(kb, in_off[tt]);
+            t.v[tt] = load_frag_at<DT>(vb, in_off[tt]);
+            t.d[tt] = load_frag_at<DT>(db, do_off[tt]);
         }
     };
 
@@ -611,12 +685,11 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_kernel(AttnArgs a) {
         if constexpr (!DUAL) {
             if (r + 1 < a.reps_per_chunk) load_tiles(r + 1, cur);
         }
+        const size_t dhead0 = (row0 * (size_t)a.ld_dqkv + h * HD) * ES<DT>;
 #pragma unroll
         for (int tj = 0; tj < 4; ++tj) {
-            const int j = 16 * tj + c;
-            const size_t off = (row0 + j) * (size_t)a.ld_dqkv + h * HD;
-            store_row8_guard<DT>(j < TOK ? a.dv : nullptr, off, g, dv[0][tj], dv[1][tj]);
-            store_row8_guard<DT>(j < TOK ? a.dk : nullptr, off, g, dk[0][tj] * a.scale, dk[1][tj] * a.scale);
+            store_row8_at<DT>(window_rsrc<DT>(a.dv, dhead0, a.ld_dqkv), dx_off[tj], g, dv[0][tj], dv[1][tj]);
+            store_row8_at<DT>(window_rsrc<DT>(a.dk, dhead0, a.ld_dqkv), dx_off[tj], g, dk[0][tj] * a.scale, dk[1][tj] * a.scale);
         }
         // dQ^T[d][i] = scale * sum_j K^T[d][j] dS^T[j][i]
         f32x4 dq[2][4];
@@ -638,9 +711,7 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_kernel(AttnArgs a) {
         }
 #pragma unroll
         for (int ti = 0; ti < 4; ++ti) {
-            const int i = 16 * ti + c;
-            store_row8_guard<DT>(i < TOK ? a.dq : nullptr, (row0 + i) * (size_t)a.ld_dqkv + h * HD, g,
-                                 dq[0][ti] * a.scale, dq[1][ti] * a.scale);
+            store_row8_at<DT>(window_rsrc<DT>(a.dq, dhead0, a.ld_dqkv), dx_off[ti], g, dq[0][ti] * a.scale, dq[1][ti] * a.scale);
         }
         if constexpr (DUAL) {
             if (r + 1 < a.reps_per_chunk) cur = nxt;
@@ -669,20 +740,31 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_kernel(AttnArgs a) {
 // the two exchange ONE partial each through LDS (wave 0 finishes dV, wave 1 finishes dK).  ~200 registers -> two waves
 // per SIMD.  K and V are loaded by both waves (second read hits L2).
 struct PairLds {
-    static constexpr int KIMG = 64 * 32 * 2;        // K image [64 keys][32] bf16 (shared: transposed reads for dQ)
-    static constexpr int HALF = 32 * 32 * 2;        // per wave: Q / dO images of its 32 query rows
-    static constexpr int TIMG = 64 * 32 * 2;        // per wave: dS^T [64 keys][32 own queries]
-    static constexpr int EXCH = 64 * 32 * 4;        // one f32 partial [64 keys][32 d]
+    static constexpr int KIMG = 64 * 64;            // K image [64 keys][32] bf16 (shared: transposed reads for dQ), img32_off
+    static constexpr int HALF = 32 * 64;            // per wave: Q / dO images of its 32 query rows, img32_off
+    static constexpr int TIMG = 64 * 64;            // per wave: dS^T [64 keys][32 own queries], timg_off
+    static constexpr int EXCH = 64 * 128;           // one f32 partial [64 keys][32 d], exch_off
     static constexpr int TAB = 2 * TABP * 4;
     static constexpr int BYTES = KIMG + 2 * (2 * HALF + TIMG) + 2 * EXCH + TAB;
 };
 
+// dS^T image: 64-byte rows of eight 8-byte units, written by columns (ds_write_b64: 16 rows, one unit) and read
+// transposed (8 rows x 4 units per half-wave).  Unit XOR (row bits 1, 3, 2): rows of equal parity within 16 get 8
+// different units (writes conflict-free), rows r, r + 4 differ in unit bit 2 (reads conflict-free).  Unchanged by +16.
+__device__ inline int timg_off(int row, int unit8) {
+    return row * 64 + ((unit8 ^ (((row >> 1) & 1) | (((row >> 3) & 1) << 1) | (((row >> 2) & 1) << 2))) << 3);
+}
+// f32 exchange rows: 128 bytes = eight 16-byte chunks, XOR row & 7 (8 rows of one ds_*_b128 group -> 8 different chunks)
+__device__ inline int exch_off(int row, int chunk16) { return row * 128 + ((chunk16 ^ (row & 7)) << 4); }
+
 // transposed read of a 32-column bf16 image with 32-row operand blocks (rows R0+{0..3}, R0+16+{0..3})
-__device__ inline Frag<PSWIN_BF16> tr32(const char* img, int ld_elems, int R0, int col0, int c) {
+template <bool TIMG>
+__device__ inline Frag<PSWIN_BF16> tr32(const char* img, int R0, int col0, int c) {
     const int q = c >> 2, p = c & 3;
     typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
-    const char* a0 = img + ((size_t)(R0 + q) * ld_elems + col0 + 4 * p) * 2;
-    const char* a1 = a0 + (size_t)16 * ld_elems * 2;
+    const int k8 = (col0 >> 2) + p;
+    const char* a0 = img + (TIMG ? timg_off(R0 + q, k8) : img32_off(R0 + q, k8 >> 1) + ((k8 & 1) << 3));
+    const char* a1 = a0 + 16 * 64;
     s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a0));
     s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(a1));
     typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -695,7 +777,7 @@ __device__ inline Frag<PSWIN_BF16> tr32(const char* img, int ld_elems, int R0, i
 __global__ __launch_bounds__(128, 2) void attn_bwd_pair_kernel(AttnArgs a) {
     constexpr int DT = PSWIN_BF16;
     __shared__ __attribute__((aligned(16))) char smem[PairLds::BYTES];
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;      // w = query half
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;      // w = query half
     const int c = lane & 15, g = lane >> 4;
     const int item = blockIdx.x;
     const int h = item % a.heads;
@@ -715,20 +797,34 @@ __global__ __launch_bounds__(128, 2) void attn_bwd_pair_kernel(AttnArgs a) {
     struct Ops {
         Frag<DT> q[2], d[2], k[4], v[4];
     };
+    unsigned kv_off[4], q_off[2], do_off[2], dkv_off[4], dq_off[2];   // per-lane byte offsets within a window
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) {
+        kv_off[tt] = row_off<DT>(16 * tt + c, a.ld_qkv, g);
+        dkv_off[tt] = (unsigned)((16 * tt + c) * a.ld_dqkv) * 2u;
+    }
+#pragma unroll
+    for (int tt = 0; tt < 2; ++tt) {
+        q_off[tt] = row_off<DT>(16 * (2 * w + tt) + c, a.ld_qkv, g);
+        do_off[tt] = row_off<DT>(16 * (2 * w + tt) + c, a.ld_out, g);
+        dq_off[tt] = (unsigned)((16 * (2 * w + tt) + c) * a.ld_dqkv) * 2u;
+    }
     auto load_ops = [&](int r, Ops& t) {
         const size_t row0 = ((size_t)(chunk * a.reps_per_chunk + r) * a.nb + wb) * TOK;
+        const size_t head0 = (row0 * (size_t)a.ld_qkv + h * HD) * 2;
+        const rsrc_t qb = window_rsrc<DT>(a.q, head0, a.ld_qkv);
+        const rsrc_t kb = window_rsrc<DT>(a.k, head0, a.ld_qkv);
+        const rsrc_t vb = window_rsrc<DT>(a.v, head0, a.ld_qkv);
+        const rsrc_t db = window_rsrc<DT>(a.dout, (row0 * (size_t)a.ld_out + h * HD) * 2, a.ld_out);
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
-            const int row = 16 * tt + c;
-            const size_t off = (row0 + row) * (size_t)a.ld_qkv + h * HD + 8 * g;
-            t.k[tt] = load_frag<DT>(a.k, off, row < TOK);
-            t.v[tt] = load_frag<DT>(a.v, off, row < TOK);
+            t.k[tt] = load_frag_at<DT>(kb, kv_off[tt]);
+            t.v[tt] = load_frag_at<DT>(vb, kv_off[tt]);
         }
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
-            const int row = 16 * (2 * w + tt) + c;
-            t.q[tt] = load_frag<DT>(a.q, (row0 + row) * (size_t)a.ld_qkv + h * HD + 8 * g, row < TOK);
-            t.d[tt] = load_frag<DT>(a.dout, (row0 + row) * (size_t)a.ld_out + h * HD + 8 * g, row < TOK);
+            t.q[tt] = load_frag_at<DT>(qb, q_off[tt]);
+            t.d[tt] = load_frag_at<DT>(db, do_off[tt]);
         }
     };
     Ops cur;
@@ -751,15 +847,16 @@ __global__ __launch_bounds__(128, 2) void attn_bwd_pair_kernel(AttnArgs a) {
     for (int r = 0; r < a.reps_per_chunk; ++r) {
         const size_t win = (size_t)(chunk * a.reps_per_chunk + r) * a.nb + wb;
         const size_t row0 = win * TOK;
+        const size_t dhead0 = (row0 * (size_t)a.ld_dqkv + h * HD) * 2;
         // LDS images for the transposed operand reads
         if (w == 0) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) *reinterpret_cast<bf16x8*>(kimg + ((size_t)(16 * t + c) * 32 + 8 * g) * 2) = cur.k[t].v;
+            for (int t = 0; t < 4; ++t) *reinterpret_cast<bf16x8*>(kimg + img32_off(16 * t + c, g)) = cur.k[t].v;
         }
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
-            *reinterpret_cast<bf16x8*>(qimg + ((size_t)(16 * tt + c) * 32 + 8 * g) * 2) = cur.q[tt].v;
-            *reinterpret_cast<bf16x8*>(doimg + ((size_t)(16 * tt + c) * 32 + 8 * g) * 2) = cur.d[tt].v;
+            *reinterpret_cast<bf16x8*>(qimg + img32_off(16 * tt + c, g)) = cur.q[tt].v;
+            *reinterpret_cast<bf16x8*>(doimg + img32_off(16 * tt + c, g)) = cur.d[tt].v;
         }
         const float* lse_row = a.lse + (win * a.heads + h) * PADT;
         Frag<DT> pf[4], dsf[4];
@@ -793,7 +890,7 @@ __global__ __launch_bounds__(128, 2) void attn_bwd_pair_kernel(AttnArgs a) {
                     gsum[tt][tj] = gsum[tt][tj] + ds4[tt][tj];
                     // dS^T[j][local i .. +3], local i = 16 tt + 4 g
                     const bf16x4 b = {(__bf16)ds4[tt][tj][0], (__bf16)ds4[tt][tj][1], (__bf16)ds4[tt][tj][2], (__bf16)ds4[tt][tj][3]};
-                    *reinterpret_cast<bf16x4*>(timg + ((size_t)(16 * tj + c) * 32 + 16 * tt + 4 * g) * 2) = b;
+                    *reinterpret_cast<bf16x4*>(timg + timg_off(16 * tj + c, 4 * tt + g)) = b;
                 }
             }
 #pragma unroll
@@ -810,8 +907,8 @@ __global__ __launch_bounds__(128, 2) void attn_bwd_pair_kernel(AttnArgs a) {
         Frag<DT> dot[2], qt[2];
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-            dot[dt] = tr32(doimg, 32, 4 * g, 16 * dt, c);
-            qt[dt] = tr32(qimg, 32, 4 * g, 16 * dt, c);
+            dot[dt] = tr32<false>(doimg, 4 * g, 16 * dt, c);
+            qt[dt] = tr32<false>(qimg, 4 * g, 16 * dt, c);
         }
         f32x4 keep[2][4];
         {
@@ -824,20 +921,21 @@ __global__ __launch_bounds__(128, 2) void attn_bwd_pair_kernel(AttnArgs a) {
                     const f32x4 dvp = mma32<DT>(dot[dt], pf[tj], z);
                     const f32x4 dkp = mma32<DT>(qt[dt], dsf[tj], z);
                     keep[dt][tj] = w == 0 ? dvp : dkp;
-                    *reinterpret_cast<f32x4*>(exch + (16 * tj + c) * 32 + 16 * dt + 4 * g) = w == 0 ? dkp : dvp;
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(exch) + exch_off(16 * tj + c, 4 * dt + g)) = w == 0 ? dkp : dvp;
                 }
         }
         __syncthreads();          // exchange written, K image written
         {
             const float* other = w == 0 ? exch_dv : exch_dk;
-            void* dst = w == 0 ? a.dv : a.dk;
+            const rsrc_t dst = window_rsrc<DT>(w == 0 ? a.dv : a.dk, dhead0, a.ld_dqkv);
             const float mul = w == 0 ? 1.0f : a.scale;
 #pragma unroll
             for (int tj = 0; tj < 4; ++tj) {
                 const int j = 16 * tj + c;
-                const f32x4 o0 = (keep[0][tj] + *reinterpret_cast<const f32x4*>(other + j * 32 + 4 * g)) * mul;
-                const f32x4 o1 = (keep[1][tj] + *reinterpret_cast<const f32x4*>(other + j * 32 + 16 + 4 * g)) * mul;
-                store_row8_guard<DT>(j < TOK ? dst : nullptr, (row0 + j) * (size_t)a.ld_dqkv + h * HD, g, o0, o1);
+                const char* ob = reinterpret_cast<const char*>(other);
+                const f32x4 o0 = (keep[0][tj] + *reinterpret_cast<const f32x4*>(ob + exch_off(j, g))) * mul;
+                const f32x4 o1 = (keep[1][tj] + *reinterpret_cast<const f32x4*>(ob + exch_off(j, 4 + g))) * mul;
+                store_row8_at<DT>(dst, dkv_off[tj], g, o0, o1);
             }
         }
         // dQ^T[d][i] = scale * sum_j K^T[d][j] dS^T[j][i] for this wave's queries
@@ -850,19 +948,17 @@ __global__ __launch_bounds__(128, 2) void attn_bwd_pair_kernel(AttnArgs a) {
         for (int s = 0; s < 2; ++s) {
             Frag<DT> kt[2];
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt) kt[dt] = tr32(kimg, 32, 32 * s + 4 * g, 16 * dt, c);
+            for (int dt = 0; dt < 2; ++dt) kt[dt] = tr32<false>(kimg, 32 * s + 4 * g, 16 * dt, c);
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
-                const Frag<DT> tf = tr32(timg, 32, 32 * s + 4 * g, 16 * tt, c);
+                const Frag<DT> tf = tr32<true>(timg, 32 * s + 4 * g, 16 * tt, c);
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) dq[dt][tt] = mma32<DT>(kt[dt], tf, dq[dt][tt]);
             }
         }
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
-            const int i = 16 * (2 * w + tt) + c;
-            store_row8_guard<DT>(i < TOK ? a.dq : nullptr, (row0 + i) * (size_t)a.ld_dqkv + h * HD, g, dq[0][tt] * a.scale,
-                                 dq[1][tt] * a.scale);
+            store_row8_at<DT>(window_rsrc<DT>(a.dq, dhead0, a.ld_dqkv), dq_off[tt], g, dq[0][tt] * a.scale, dq[1][tt] * a.scale);
         }
         __syncthreads();          // both waves are done with the K image and the exchange buffers
     }
