@@ -173,6 +173,31 @@ int pswin_bn_relu_bwd(const void* dz, const void* y, int dtype, const float* gam
                       const float* save_mean, const float* save_rstd, int train, void* dy, float* dgamma, float* dbeta,
                       float* workspace, long long M, int C, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Fused PatchEmbed stem (HOT:742-750: Conv3x3(3->32) BN ReLU Conv3x3(32->64) BN ReLU Conv4x4/s4(64->96)), bf16
+ * operands / f32 accumulation, specialised for embed_dim 96, in_chans 3, patch_size 4.  Only y2 (the second
+ * convolution's output) is ever stored at full resolution; see csrc/pswin_stem.hip for the data flow.
+ * Packed operands (bf16): x4 [B][H][W][4] (channel 3 = 1), w1p [32][12][4] (tap-major, taps 9..11 / channel 3 zero),
+ * w2p [9][64 out][32 in], w2t [9][32 in][64 out], w3p [16][96 out][64 in], w3t [16][64 in][96 out].
+ * scale / shift: the BatchNorm folded to z = scale * y + shift per channel (f32).  workspace: f32,
+ * pswin_stem_workspace(B, H, W) elements.
+ * ---------------------------------------------------------------------------------------------- */
+int pswin_stem_workspace(int B, int H, int W);
+/* [B,3,H,W] f32 -> x4 */
+int pswin_stem_pack_input(const float* x, int B, int H, int W, void* x4, void* stream);
+/* sums: f32 [64 + 48*48]: per-channel sum / sum of squares of y1 = conv1(x) over all pixels (y1 is not stored), then
+ * (want_xx) the input autocorrelation XX[k][k'] = sum_p xp[p][k] xp[p][k'] over the 48 tap-channel slots (slot
+ * 4*4+3, the centre tap's ones channel, yields the plain sums and the pixel count) used by the backward pass. */
+int pswin_stem_conv1_stats(const void* x4, const void* w1p, int B, int H, int W, int want_xx, float* sums,
+                           float* workspace, void* stream);
+/* y2 = conv2(relu(scale1 * conv1(x) + shift1)) (no bias), [B][H][W][64] bf16; sums2 (may be NULL): f32 [128] per-channel
+ * sum / sum of squares of y2. */
+int pswin_stem_conv2_fwd(const void* x4, const void* w1p, const float* scale1, const float* shift1, const void* w2p, int B,
+                         int H, int W, void* y2, float* sums2, float* workspace, void* stream);
+/* tokens[B*H/4*W/4][96] bf16 = conv3(relu(scale2 * y2 + shift2)) + bias3 */
+int pswin_stem_conv3_fwd(const void* y2, const float* scale2, const float* shift2, const void* w3p, const float* bias3,
+                         int B, int H, int W, void* tokens, void* stream);
+
 /* Column sums of a row-major [M, N] matrix in fp32: out[n] = sum_m x[m][n] (fixed summation order).  The bias
  * gradient of every Linear on the path (autograd of nn.Linear, HOT:50-52, 236, 323) and the reduction of split-K
  * weight-gradient partials.  N % 8 == 0; workspace: f32, pswin_colsum_workspace(M, N, dtype) elements. */

@@ -38,6 +38,11 @@ _PROTOTYPES = {
     "pswin_bn_workspace": [_i],
     "pswin_bn_relu_fwd": [_vp, _i, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _vp],
     "pswin_bn_relu_bwd": [_vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _vp],
+    "pswin_stem_workspace": [_i, _i, _i],
+    "pswin_stem_pack_input": [_vp, _i, _i, _i, _vp, _vp],
+    "pswin_stem_conv1_stats": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
+    "pswin_stem_conv2_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "pswin_stem_conv3_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     "pswin_colsum_workspace": [ctypes.c_longlong, _i, _i],
     "pswin_colsum": [_vp, _i, ctypes.c_longlong, _i, _vp, _vp, _vp],
     "pswin_interp_rows": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
