@@ -198,6 +198,28 @@ int pswin_stem_conv2_fwd(const void* x4, const void* w1p, const float* scale1, c
 int pswin_stem_conv3_fwd(const void* y2, const float* scale2, const float* shift2, const void* w3p, const float* bias3,
                          int B, int H, int W, void* tokens, void* stream);
 
+/* Backward of the stem.  dtok: [M][96] bf16 gradient of the tokens.
+ * conv3_bwd_stats: g2 = (dtok . W3)[pixel] * [scale2 y2 + shift2 > 0]; sums f32 [128] = per-channel sum g2 (= dbeta2),
+ *   sum g2 * yhat2 (= dgamma2), yhat2 = a y2 + b.  prm: f32 [4][64] = scale2, shift2, a = rstd2, b = -mean2 rstd2.
+ * conv3_bwd_data: dy2 = k1 g2 - P y2 - Q, [B][H][W][64] bf16.  prm: f32 [5][64] = scale2, shift2, k1, P, Q
+ *   (training-mode BatchNorm backward: k1 = gamma rstd, P = k1 a mean(g2 yhat2), Q = k1 (mean g2 + b mean(g2 yhat2))).
+ * conv3_wgrad: dw3 f32 [4 ky][2][48][256] accumulator tiles (decoded by the host: stem.decode_dw3) of
+ *   sum_tokens dtok (x) relu(scale2 y2 + shift2) patches.
+ * conv2_wgrad: dw2 f32 [2][36][256] accumulator tiles (stem.decode_dw2) of sum_p dy2[p] (x) a1[p + tap], a1 recomputed.
+ * conv2_bwd: out f32 [64 + 32*48]: sum g1 (= dbeta1), sum g1 * yhat1 (= dgamma1), G[ch][slot] = sum_p g1[p][ch] xp[p][slot]
+ *   with g1 = conv2 data gradient of dy2 masked by relu(bn1 y1) > 0, never stored.  prm: f32 [4][32] = scale1, shift1,
+ *   a = rstd1, b = -mean1 rstd1. */
+int pswin_stem_conv3_bwd_stats(const void* dtok, const void* y2, const float* prm, const void* w3t, int B, int H, int W,
+                               float* sums, float* workspace, void* stream);
+int pswin_stem_conv3_bwd_data(const void* dtok, const void* y2, const float* prm, const void* w3t, int B, int H, int W,
+                              void* dy2, void* stream);
+int pswin_stem_conv3_wgrad(const void* dtok, const void* y2, const float* scale2, const float* shift2, int B, int H, int W,
+                           float* dw3, float* workspace, void* stream);
+int pswin_stem_conv2_wgrad(const void* x4, const void* w1p, const float* scale1, const float* shift1, const void* dy2, int B,
+                           int H, int W, float* dw2, float* workspace, void* stream);
+int pswin_stem_conv2_bwd(const void* x4, const void* w1p, const float* prm, const void* dy2, const void* w2t, int B, int H,
+                         int W, float* out, float* workspace, void* stream);
+
 /* Column sums of a row-major [M, N] matrix in fp32: out[n] = sum_m x[m][n] (fixed summation order).  The bias
  * gradient of every Linear on the path (autograd of nn.Linear, HOT:50-52, 236, 323) and the reduction of split-K
  * weight-gradient partials.  N % 8 == 0; workspace: f32, pswin_colsum_workspace(M, N, dtype) elements. */

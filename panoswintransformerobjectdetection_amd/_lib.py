@@ -43,6 +43,11 @@ _PROTOTYPES = {
     "pswin_stem_conv1_stats": [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp],
     "pswin_stem_conv2_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "pswin_stem_conv3_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
+    "pswin_stem_conv3_bwd_stats": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
+    "pswin_stem_conv3_bwd_data": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
+    "pswin_stem_conv3_wgrad": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
+    "pswin_stem_conv2_wgrad": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
+    "pswin_stem_conv2_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
     "pswin_colsum_workspace": [ctypes.c_longlong, _i, _i],
     "pswin_colsum": [_vp, _i, ctypes.c_longlong, _i, _vp, _vp, _vp],
     "pswin_interp_rows": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],

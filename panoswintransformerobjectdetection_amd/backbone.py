@@ -26,7 +26,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 import torch.utils.checkpoint as checkpoint
 
-from . import geometry, ops
+from . import geometry, ops, stem
 from ._lib import HEAD_DIM, WS, WTOK, PswinError
 from .registry import BACKBONES
 
@@ -337,6 +337,12 @@ class PatchEmbed(nn.Module):
             x = F.pad(x, (0, pw - W % pw))
         if H % ph:
             x = F.pad(x, (0, 0, 0, ph - H % ph))
+        if stem.stem_supported(self.proj, x, cd):            # fused HIP stem (csrc/pswin_stem.hip): y2 is the only
+            B, Wh, Ww = x.shape[0], x.shape[2] // ph, x.shape[3] // pw    # full-resolution tensor ever stored
+            tok = stem.stem_forward(self.proj, x, self.training).view(B, Wh * Ww, self.embed_dim)
+            if self.norm is not None:
+                tok = ops.layer_norm_gather(tok, self.norm.weight, self.norm.bias, self.norm.eps, out_dtype=torch.float32)
+            return tok.float(), Wh, Ww
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=(cd == torch.bfloat16)):
             x = x.contiguous(memory_format=torch.channels_last)                 # bf16: MIOpen NHWC bf16 convolutions
             mods = list(self.proj)

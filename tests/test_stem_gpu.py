@@ -72,3 +72,110 @@ def test_stem_forward_pieces(B, H, W):
     tk = stem.conv3_fwd(y2k.permute(0, 2, 3, 1).to(torch.bfloat16).contiguous(), sc2, sh2, stem.pack_taps(w3, False), b3)
     tk = tk.float().view(B, H // 4, W // 4, 96).permute(0, 3, 1, 2)
     assert torch.allclose(tk, t_ref, rtol=1e-2, atol=2e-2)
+
+
+def _relerr(a, b):
+    return float((a - b).norm() / b.norm().clamp_min(1e-12))
+
+
+@pytest.mark.parametrize("B,H,W", SHAPES)
+def test_stem_backward_pieces(B, H, W):
+    stem, x, w1, w2, w3, b3, sc1, sh1, sc2, sh2 = _setup(B, H, W, seed=1)
+    dev = x.device
+    g = torch.Generator().manual_seed(5)
+    y1, a1, y2, a2, t = _ref_forward(x, w1, w2, w3, b3, sc1, sh1, sc2, sh2)
+    ws = stem.workspace(x)
+    x4 = stem.pack_input(x)
+    w1p = stem.pack_w1(w1)
+    y2k = _r(y2).permute(0, 2, 3, 1).to(torch.bfloat16).contiguous()               # the stored activation
+    y2r = y2k.float().permute(0, 3, 1, 2)
+    M = B * (H // 4) * (W // 4)
+    dtok = (torch.randn(M, 96, generator=g) * 0.5).to(dev).to(torch.bfloat16)
+    dt_img = dtok.float().view(B, H // 4, W // 4, 96).permute(0, 3, 1, 2)
+    mean2 = (torch.randn(64, generator=g) * 0.2).to(dev)
+    rstd2 = (torch.rand(64, generator=g) + 0.5).to(dev)
+    # conv3 data gradient + BN2 backward sums
+    da2 = F.conv_transpose2d(dt_img, _r(w3), stride=4)
+    z2 = y2r * sc2[None, :, None, None] + sh2[None, :, None, None]
+    g2 = da2 * (z2 > 0)
+    yh2 = (y2r - mean2[None, :, None, None]) * rstd2[None, :, None, None]
+    prm = torch.stack([sc2, sh2, rstd2, -mean2 * rstd2]).contiguous()
+    sums = stem.conv3_bwd_stats(dtok, y2k, prm, stem.pack_taps(w3, True), ws)
+    n = B * H * W
+    assert torch.allclose(sums[:64], g2.sum((0, 2, 3)), rtol=2e-3, atol=2e-3 * n ** 0.5)
+    assert torch.allclose(sums[64:], (g2 * yh2).sum((0, 2, 3)), rtol=2e-3, atol=2e-3 * n ** 0.5)
+    # dy2 = k1 g2 - P y2 - Q
+    k1 = (torch.rand(64, generator=g) + 0.5).to(dev)
+    Pv = (torch.randn(64, generator=g) * 0.05).to(dev)
+    Qv = (torch.randn(64, generator=g) * 0.05).to(dev)
+    prm5 = torch.stack([sc2, sh2, k1, Pv, Qv]).contiguous()
+    dy2k = stem.conv3_bwd_data(dtok, y2k, prm5, stem.pack_taps(w3, True))
+    dy2_ref = k1[None, :, None, None] * g2 - Pv[None, :, None, None] * y2r - Qv[None, :, None, None]
+    assert torch.allclose(dy2k.float().permute(0, 3, 1, 2), dy2_ref, rtol=1e-2, atol=1e-2)
+    # conv3 weight gradient
+    a2r = _r(torch.relu(z2))
+    dw3_ref = torch.nn.grad.conv2d_weight(a2r, w3.shape, dt_img, stride=4)
+    dw3 = stem.conv3_wgrad(dtok, y2k, sc2, sh2, ws)
+    assert _relerr(dw3, dw3_ref) < 2e-3
+    # conv2 weight gradient (a1 recomputed in-kernel) and data gradient pieces, on a bf16 dy2
+    dy2b = dy2k
+    dy2f = dy2b.float().permute(0, 3, 1, 2)
+    dw2_ref = torch.nn.grad.conv2d_weight(a1, w2.shape, dy2f, padding=1)
+    dw2 = stem.conv2_wgrad(x4, w1p, sc1, sh1, dy2b, ws)
+    assert _relerr(dw2, dw2_ref) < 3e-3
+    mean1 = (torch.randn(32, generator=g) * 0.2).to(dev)
+    rstd1 = (torch.rand(32, generator=g) + 0.5).to(dev)
+    prm1 = torch.stack([sc1, sh1, rstd1, -mean1 * rstd1]).contiguous()
+    sg, sgy, G = stem.conv2_bwd(x4, w1p, prm1, dy2b, stem.pack_taps(w2, True), ws)
+    da1 = torch.nn.grad.conv2d_input(a1.shape, _r(w2), dy2f, padding=1)
+    z1 = y1 * sc1[None, :, None, None] + sh1[None, :, None, None]
+    g1 = da1 * (z1 > 0)
+    yh1 = (y1 - mean1[None, :, None, None]) * rstd1[None, :, None, None]
+    assert _relerr(sg, g1.sum((0, 2, 3))) < 5e-3
+    assert _relerr(sgy, (g1 * yh1).sum((0, 2, 3))) < 5e-3
+    x4f = x4.float().permute(0, 3, 1, 2)
+    patches = F.unfold(x4f, 3, padding=1).view(B, 4, 9, H * W).permute(0, 3, 2, 1).reshape(n, 36)
+    G_ref = torch.zeros(32, 48, device=dev)
+    G_ref[:, :36] = _r(g1).permute(0, 2, 3, 1).reshape(n, 32).T @ patches
+    assert _relerr(G, G_ref) < 5e-3
+
+
+@pytest.mark.parametrize("B,H,W,train", [(2, 40, 72, True), (2, 32, 64, False), (3, 52, 100, True)])
+def test_stem_module_end_to_end(B, H, W, train):
+    """PatchEmbed with the fused bf16 stem against the same module in fp32 (library convolutions): tokens, every
+    parameter gradient, the BatchNorm running statistics.  Gradients through two BatchNorm + ReLU stages amplify bf16
+    operand rounding (ReLU masks flip): the yardstick is the library bf16 path of the same module, measured the same
+    way -- the fused path must be as close to fp32 as that one (x 1.5 + 1 % slack; measured: equal or slightly closer)."""
+    import copy
+    from panoswintransformerobjectdetection_amd.backbone import PatchEmbed
+    torch.manual_seed(3)
+    dev = "cuda:0"
+    ref = PatchEmbed(4, 3, 96, norm=True).to(dev)
+    with torch.no_grad():
+        for m in ref.proj:
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.uniform_(0.5, 1.5)
+                m.bias.normal_(0, 0.2)
+                m.running_mean.normal_(0, 0.1)
+                m.running_var.uniform_(0.5, 1.5)
+    fused, lib = copy.deepcopy(ref), copy.deepcopy(ref)
+    for m in (ref, fused, lib):
+        m.train(train)
+    x = torch.randn(B, 3, H, W, device=dev)
+    gout = torch.randn(B, (H // 4) * (W // 4), 96, device=dev)
+    t_ref, _, _ = ref(x, torch.float32)
+    t_fus, Wh, Ww = fused(x, torch.bfloat16)
+    t_lib, _, _ = lib(x.clone().requires_grad_(True), torch.bfloat16)      # an image that needs a gradient: library path
+    assert (Wh, Ww) == (H // 4, W // 4)
+    assert torch.allclose(t_fus, t_ref, atol=3e-2, rtol=3e-2)
+    for t in (t_ref, t_fus, t_lib):
+        (t * gout).sum().backward()
+    for (name, p_ref), (_, p_fus), (_, p_lib) in zip(ref.named_parameters(), fused.named_parameters(), lib.named_parameters()):
+        assert p_fus.grad is not None, name
+        if train and name in ("proj.0.bias", "proj.3.bias"):       # no gradient through a BatchNorm in training mode
+            assert float(p_fus.grad.abs().max()) == 0.0
+            continue
+        e_fus, e_lib = _relerr(p_fus.grad, p_ref.grad), _relerr(p_lib.grad, p_ref.grad)
+        assert e_fus < 1.5 * e_lib + 0.01, (name, e_fus, e_lib)
+    for (name, b_ref), (_, b_fus) in zip(ref.named_buffers(), fused.named_buffers()):
+        assert torch.allclose(b_fus.float(), b_ref.float(), rtol=1e-2, atol=1e-3), name
