@@ -203,7 +203,7 @@ int pswin_stem_conv3_fwd(const void* y2, const float* scale2, const float* shift
  *   sum g2 * yhat2 (= dgamma2), yhat2 = a y2 + b.  prm: f32 [4][64] = scale2, shift2, a = rstd2, b = -mean2 rstd2.
  * conv3_bwd_data: dy2 = k1 g2 - P y2 - Q, [B][H][W][64] bf16.  prm: f32 [5][64] = scale2, shift2, k1, P, Q
  *   (training-mode BatchNorm backward: k1 = gamma rstd, P = k1 a mean(g2 yhat2), Q = k1 (mean g2 + b mean(g2 yhat2))).
- * conv3_wgrad: dw3 f32 [4 ky][2][48][256] accumulator tiles (decoded by the host: stem.decode_dw3) of
+ * conv3_wgrad: dw3 f32 [4 ky][8 waves][12][256] accumulator tiles (decoded by the host: stem.decode_dw3) of
  *   sum_tokens dtok (x) relu(scale2 y2 + shift2) patches.
  * conv2_wgrad: dw2 f32 [2][36][256] accumulator tiles (stem.decode_dw2) of sum_p dy2[p] (x) a1[p + tap], a1 recomputed.
  * conv2_bwd: out f32 [64 + 32*48]: sum g1 (= dbeta1), sum g1 * yhat1 (= dgamma1), G[ch][slot] = sum_p g1[p][ch] xp[p][slot]

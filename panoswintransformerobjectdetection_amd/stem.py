@@ -84,15 +84,15 @@ def conv3_bwd_data(dtok, y2, prm, w3t):
 
 
 def decode_dw3(raw):
-    """accumulator tiles [ky][th][j][nt][mt][e][g][c] -> [96 out][64 in][4][4]; out = 16 mt + 4 g + e, in = 16 nt + c,
-    kx = 2 th + j"""
-    t = raw.view(4, 2, 2, 4, 6, 4, 4, 16)
-    return t.permute(4, 6, 5, 3, 7, 0, 1, 2).reshape(C3, C2, 4, 4)
+    """accumulator tiles [ky][nh][kx][nt][mt][e][g][c] -> [96 out][64 in][4][4]; out = 16 mt + 4 g + e,
+    in = 16 (2 nh + nt) + c  (wave = kx + 4 nh)"""
+    t = raw.view(4, 2, 4, 2, 6, 4, 4, 16)
+    return t.permute(4, 6, 5, 1, 3, 7, 0, 2).reshape(C3, C2, 4, 4)
 
 
 def conv3_wgrad(dtok, y2, scale2, shift2, ws):
     B, H, W, _ = y2.shape
-    raw = torch.empty(4 * 2 * 48 * 256, device=y2.device, dtype=torch.float32)
+    raw = torch.empty(4 * 8 * 12 * 256, device=y2.device, dtype=torch.float32)
     _lib.call("pswin_stem_conv3_wgrad", y2, _ptr(dtok), _ptr(y2), _ptr(scale2), _ptr(shift2), B, H, W, _ptr(raw), _ptr(ws))
     return decode_dw3(raw)
 
