@@ -125,10 +125,12 @@ int pswin_ln_gather_fwd(const void* x, int x_dtype, const int32_t* map, const fl
 /* Its backward: for every token (b, t), dy row = dy[b][inv ? inv[t] : t] and
  *   dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma, xhat = (x - mean) * rstd;
  *   dgamma = sum dy * xhat, dbeta = sum dy (block partials in `workspace`, reduced in a fixed order).
+ * dres (may be NULL; f32 [B, S, C], needs x_dtype f32): the gradient reaching x along the residual shortcut
+ * (x + DropPath(f(norm(x))), HOT:533-536); it is added into dx here, which replaces autograd's separate accumulation pass.
  * dy: [B, n_out, C] dy_dtype; dx: [B, S, C] x_dtype; workspace: f32, pswin_ln_workspace(B * S, C) elements. */
 int pswin_ln_gather_bwd(const void* dy, int dy_dtype, const int32_t* inv, const void* x, int x_dtype, const float* mean,
-                        const float* rstd, const float* gamma, void* dx, float* dgamma, float* dbeta, float* workspace,
-                        int B, int S, int n_out, int C, void* stream);
+                        const float* rstd, const float* gamma, const float* dres, void* dx, float* dgamma, float* dbeta,
+                        float* workspace, int B, int S, int n_out, int C, void* stream);
 
 /* Workspace elements for the LayerNorm backward kernels over `rows` walked rows of width C. */
 int pswin_ln_workspace(long long rows, int C);

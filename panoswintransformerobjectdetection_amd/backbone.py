@@ -178,7 +178,8 @@ class PanoSwinTransformerBlock(nn.Module, DoubleModeModule):
             mask = ops.planar_mask_tiles(H, W, self.shift_size, dev) if self.shift_size else None   # HOT:474
         a = self.attn
         n1 = self.norm1                                                           # norm1 + shift + pad + partition
-        win = ops.layer_norm_gather(x, n1.weight, n1.bias, n1.eps, wmap, inv, cd)  # [B, nW*49, C]
+        # the second result is x itself: using it for the shortcut folds the shortcut's gradient into the LN backward kernel
+        win, x = ops.layer_norm_gather(x, n1.weight, n1.bias, n1.eps, wmap, inv, cd, passthrough=True)  # [B, nW*49, C]
         qkv = _linear(win.view(-1, C), a.qkv, cd)                                 # [B*nW*49, 3C]
         att = ops.window_attention(qkv, a.sphere_position_alpha_table_Te, a.sphere_position_beta_table_Te, dist, mask,
                                    a.num_heads, a.scale, nW)
@@ -186,7 +187,8 @@ class PanoSwinTransformerBlock(nn.Module, DoubleModeModule):
         scale = _drop_path_scale(x, self.drop_path_p, self.training)
         x = ops.window_scatter_add(att, x, wmap, inv, scale)                      # shortcut + DropPath(attn)
         n2 = self.norm2
-        y = self.mlp(ops.layer_norm_gather(x, n2.weight, n2.bias, n2.eps, out_dtype=cd), cd)
+        h, x = ops.layer_norm_gather(x, n2.weight, n2.bias, n2.eps, out_dtype=cd, passthrough=True)
+        y = self.mlp(h, cd)
         ident = ops.identity_map(S, dev)                                          # x + DropPath(mlp): one row kernel
         return ops.window_scatter_add(y, x, ident, ident, scale)
 
@@ -243,7 +245,8 @@ class PitchAttentionModule(WindowAttention):
         att = _linear(att, self.proj, cd).view(B, nW * WTOK, C)
         # the reference overwrites its own shortcut with LN(x) (in-place norm on a view, HOT:1154-1155): residual = xn
         x = ops.window_scatter_add(att, xn, wmap, inv, None)
-        y = self.mlp(ops.layer_norm_gather(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, out_dtype=cd), cd)
+        h, x = ops.layer_norm_gather(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, out_dtype=cd, passthrough=True)
+        y = self.mlp(h, cd)
         ident = ops.identity_map(S, dev)
         return ops.window_scatter_add(y, x, ident, ident, None)
 
@@ -287,15 +290,22 @@ class BasicLayer(nn.Module, DoubleModeModule):
         for blk in self.blocks:
             blk.set_pano_mode(pano_mode)
 
-    def forward(self, x, H, W, cd):
+    def forward(self, x, H, W, cd, out_norm=None):
+        """-> (stage output [normed by out_norm if given], H, W, input of the next stage, its H, W)"""
         for blk in self.blocks:
             if self.use_checkpoint:
                 x = checkpoint.checkpoint(blk, x, H, W, cd, use_reentrant=False)
             else:
                 x = blk(x, H, W, cd)
+        y = x
+        if out_norm is not None:                    # output norm first: the downsample branch's gradient then joins
+            if self.downsample is not None:         # the stream inside the norm's backward kernel
+                y, x = ops.layer_norm_gather(x, out_norm.weight, out_norm.bias, out_norm.eps, passthrough=True)
+            else:
+                y = ops.layer_norm_gather(x, out_norm.weight, out_norm.bias, out_norm.eps)
         if self.downsample is None:
-            return x, H, W, x, H, W
-        return x, H, W, self.downsample(x, H, W, cd), (H + 1) // 2, (W + 1) // 2
+            return y, H, W, x, H, W
+        return y, H, W, self.downsample(x, H, W, cd), (H + 1) // 2, (W + 1) // 2
 
 
 class _ChannelBias(torch.autograd.Function):
@@ -474,10 +484,9 @@ class SimplePanoSwinTransformer(nn.Module, DoubleModeModule):
             x = x + F.linear(feat, self.abs_encoder.weight, self.abs_encoder.bias)[None]
         outs = []
         for i, layer in enumerate(self.layers):
-            x_out, H, W, x, Wh, Ww = layer(x, Wh, Ww, cd)
-            if i in self.out_indices:
-                nl = getattr(self, f"norm{i}")
-                y = ops.layer_norm_gather(x_out, nl.weight, nl.bias, nl.eps)
+            nl = getattr(self, f"norm{i}") if i in self.out_indices else None
+            y, H, W, x, Wh, Ww = layer(x, Wh, Ww, cd, nl)
+            if nl is not None:
                 outs.append(y.view(-1, H, W, self.num_features[i]).permute(0, 3, 1, 2).contiguous())
         return tuple(outs)
 

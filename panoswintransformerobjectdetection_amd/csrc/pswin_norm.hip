@@ -123,7 +123,8 @@ __global__ __launch_bounds__(THREADS) void ln_bwd_kernel(const void* __restrict_
                                                          const float* __restrict__ mean,
                                                          const float* __restrict__ rstd,
                                                          const float* __restrict__ gamma, void* __restrict__ dx,
-                                                         float* __restrict__ part, long long rows, int C) {
+                                                         const float* __restrict__ dres, float* __restrict__ part,
+                                                         long long rows, int C) {
     constexpr int RPB = THREADS / L;
     __shared__ float red[2][THREADS * 4];      // [row group][lane][4 elements] of one chunk column at a time
     const int lane = threadIdx.x % L;
@@ -168,8 +169,12 @@ __global__ __launch_bounds__(THREADS) void ln_bwd_kernel(const void* __restrict_
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             const int ch = lane + k * L;
-            if (ch < nchunks && offs[k] >= 0)
-                store4<XDT>(dx, img_in + (size_t)offs[k], (g[k] - s1 - xh[k] * s2) * rs_);
+            if (ch < nchunks && offs[k] >= 0) {
+                f32x4 v = (g[k] - s1 - xh[k] * s2) * rs_;
+                // the gradient that reaches x along the residual shortcut, added here instead of in a separate pass
+                if (dres) v = v + *reinterpret_cast<const f32x4*>(dres + img_in + (size_t)offs[k]);
+                store4<XDT>(dx, img_in + (size_t)offs[k], v);
+            }
         }
     }
     // block reduction of dgamma / dbeta over the RPB row groups (fixed order), then one partial row per block
@@ -276,16 +281,16 @@ int launch_fwd(int L, const void* x, const RowSrc& rs, const float* gamma, const
 
 template <int MODE, int DYDT, int XDT>
 int launch_bwd(int L, const void* dy, const int32_t* inv, const void* x, const RowSrc& rs, const float* mean,
-               const float* rstd, const float* gamma, void* dx, float* part, long long rows, int C, int blocks,
-               hipStream_t st) {
+               const float* rstd, const float* gamma, void* dx, const float* dres, float* part, long long rows, int C,
+               int blocks, hipStream_t st) {
 #define PSWIN_LN_BWD(LL)                                                                                          \
     case LL:                                                                                                      \
         hipLaunchKernelGGL((ln_bwd_kernel<MODE, DYDT, XDT, LL, 4>), dim3(blocks), dim3(THREADS), 0, st, dy, inv, \
-                           x, rs, mean, rstd, gamma, dx, part, rows, C);                                          \
+                           x, rs, mean, rstd, gamma, dx, dres, part, rows, C);                                    \
         break;
     if (wide_row(C)) {
         hipLaunchKernelGGL((ln_bwd_kernel<MODE, DYDT, XDT, 64, 8>), dim3(blocks), dim3(THREADS), 0, st, dy, inv, x, rs,
-                           mean, rstd, gamma, dx, part, rows, C);
+                           mean, rstd, gamma, dx, dres, part, rows, C);
         PSWIN_LAUNCH_RET();
     }
     switch (L) {
@@ -328,19 +333,21 @@ extern "C" int pswin_ln_gather_fwd(const void* x, int x_dtype, const int32_t* ma
 }
 
 extern "C" int pswin_ln_gather_bwd(const void* dy, int dy_dtype, const int32_t* inv, const void* x, int x_dtype,
-                                   const float* mean, const float* rstd, const float* gamma, void* dx, float* dgamma,
-                                   float* dbeta, float* workspace, int B, int S, int n_out, int C, void* stream) {
+                                   const float* mean, const float* rstd, const float* gamma, const float* dres,
+                                   void* dx, float* dgamma, float* dbeta, float* workspace, int B, int S, int n_out,
+                                   int C, void* stream) {
     PSWIN_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && workspace && B > 0 && S > 0 && n_out > 0);
     PSWIN_CHECK_ARG(valid_dtype(x_dtype) && valid_dtype(dy_dtype));
     PSWIN_CHECK_ARG(C >= 8 && C % 8 == 0 && C <= MAX_C && aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(gamma));
     PSWIN_CHECK_ARG(inv || n_out == S);
+    PSWIN_CHECK_ARG(!dres || (x_dtype == PSWIN_F32 && aligned16(dres)));
     RowSrc rs = {0, nullptr, S, n_out, 0, 0, 0};
     const long long rows = (long long)B * S;
     const int L = pick_lanes(C);
     const int blocks = bwd_blocks(rows, L);
     int rc = dispatch2(dy_dtype, x_dtype, [&](auto dd, auto xd) {
-        return launch_bwd<0, decltype(dd)::value, decltype(xd)::value>(L, dy, inv, x, rs, mean, rstd, gamma, dx, workspace,
-                                                                       rows, C, blocks, (hipStream_t)stream);
+        return launch_bwd<0, decltype(dd)::value, decltype(xd)::value>(L, dy, inv, x, rs, mean, rstd, gamma, dx, dres,
+                                                                       workspace, rows, C, blocks, (hipStream_t)stream);
     });
     if (rc) return rc;
     // partial rows are [dgamma(C) | dbeta(C)]; the two outputs may live in different buffers -> two column sums
@@ -379,7 +386,8 @@ extern "C" int pswin_ln_patch_merge_bwd(const void* dy, int dy_dtype, const void
     const int blocks = bwd_blocks(rows, L);
     int rc = dispatch2(dy_dtype, x_dtype, [&](auto dd, auto xd) {
         return launch_bwd<1, decltype(dd)::value, decltype(xd)::value>(L, dy, nullptr, x, rs, mean, rstd, gamma, dx,
-                                                                       workspace, rows, C4, blocks, (hipStream_t)stream);
+                                                                       nullptr, workspace, rows, C4, blocks,
+                                                                       (hipStream_t)stream);
     });
     if (rc) return rc;
     launch_colsum_2(workspace, blocks, C4, dgamma, dbeta, (hipStream_t)stream);

@@ -9,7 +9,7 @@ import math
 import torch
 
 from . import _lib
-from ._lib import BF16, F32, MODE_PANO, MODE_PLANAR, WPAD, WTOK, call, dtype_code, ptr
+from ._lib import BF16, F32, MODE_PANO, MODE_PLANAR, WPAD, WTOK, PswinError, call, dtype_code, ptr
 
 _CACHE = {}
 
@@ -192,7 +192,7 @@ def patch_merge_gather(x, H, W, out_dtype=None):
 
 class _LayerNormGather(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, wmap, inv, out_dtype):
+    def forward(ctx, x, gamma, beta, eps, wmap, inv, out_dtype, passthrough):
         B, S, C = x.shape
         x = x.contiguous()
         n_out = S if wmap is None else wmap.numel()
@@ -204,26 +204,38 @@ class _LayerNormGather(torch.autograd.Function):
              algo_bytes=B * C * (min(S, n_out) * x.element_size() + n_out * y.element_size()))
         ctx.save_for_backward(x, gamma, mean, rstd, inv)
         ctx.n_out = n_out
+        if passthrough:
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dres=None):
         x, gamma, mean, rstd, inv = ctx.saved_tensors
         B, S, C = x.shape
-        dy = dy.contiguous()
         dx = torch.empty_like(x)
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        if dy is None:                                   # only the shortcut was used downstream
+            return dres, torch.zeros_like(gamma), torch.zeros_like(gamma), None, None, None, None, None
+        dy = dy.contiguous()
+        if dres is not None:
+            if x.dtype != torch.float32:
+                raise PswinError("the residual passthrough of layer_norm_gather needs an fp32 residual stream")
+            dres = dres.float().contiguous()
         ws = torch.empty(_lib.load().pswin_ln_workspace(B * S, C), dtype=torch.float32, device=x.device)
         call("pswin_ln_gather_bwd", x, ptr(dy), dtype_code(dy), ptr(inv), ptr(x), dtype_code(x), ptr(mean), ptr(rstd),
-             ptr(gamma), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(ws), B, S, ctx.n_out, C,
-             algo_bytes=B * S * C * (dy.element_size() + 2 * x.element_size()))
-        return dx, dgamma, dbeta, None, None, None, None
+             ptr(gamma), ptr(dres), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(ws), B, S, ctx.n_out, C,
+             algo_bytes=B * S * C * (dy.element_size() + (2 if dres is None else 3) * x.element_size()))
+        return dx, dgamma, dbeta, None, None, None, None, None
 
 
-def layer_norm_gather(x, gamma, beta, eps, wmap=None, inv=None, out_dtype=None):
+def layer_norm_gather(x, gamma, beta, eps, wmap=None, inv=None, out_dtype=None, passthrough=False):
     """LayerNorm over the last dim of x [B, S, C], written through a window map (norm1 + shift + pad + window
-    partition, HOT:503-513) or in place order (wmap=None: norm2 / output norms).  Padding slots are zero rows."""
-    return _LayerNormGather.apply(x, gamma, beta, eps, wmap, inv, out_dtype or x.dtype)
+    partition, HOT:503-513) or in place order (wmap=None: norm2 / output norms).  Padding slots are zero rows.
+
+    passthrough=True returns (y, x'): x' is x itself, to be used for the residual shortcut (x' + f(y)); the gradient
+    that flows back into x' is then added to dx INSIDE the LayerNorm backward kernel instead of by a separate
+    accumulation pass over the residual stream (one per block half in the reference's autograd graph)."""
+    return _LayerNormGather.apply(x, gamma, beta, eps, wmap, inv, out_dtype or x.dtype, passthrough)
 
 
 class _LayerNormPatchMerge(torch.autograd.Function):

@@ -147,6 +147,37 @@ def test_layer_norm_gather(ops, C, xdt, ydt, use_map):
     assert torch.allclose(bd.grad.cpu(), br.grad, rtol=1e-4, atol=1e-4 * br.grad.abs().max().item())
 
 
+@pytest.mark.parametrize("C", [96, 768])
+@pytest.mark.parametrize("use_map", [False, True])
+def test_layer_norm_gather_passthrough(ops, C, use_map):
+    """x' of layer_norm_gather(..., passthrough=True) is x; the gradient sent into x' comes back added to dx (done inside
+    the backward kernel): identical to the plain two-consumer graph."""
+    B, H, W = 2, 13, 25
+    x = det_uniform((B, H * W, C), "lnp:x", 2.0) + 0.3
+    gamma, beta = det_uniform((C,), "lnp:g", 0.5, 1.0), det_uniform((C,), "lnp:b", 0.5)
+    wmap, inv, nW = ops.window_maps(True, H, W, 3, DEV) if use_map else (None, None, 0)
+    gx = det_uniform((B, H * W, C), "lnp:gx").to(DEV)
+    res = []
+    for fused in (False, True):
+        xd = x.to(DEV).requires_grad_(True)
+        gd, bd = gamma.to(DEV).requires_grad_(True), beta.to(DEV).requires_grad_(True)
+        if fused:
+            y, x2 = ops.layer_norm_gather(xd, gd, bd, 1e-5, wmap, inv, torch.bfloat16, passthrough=True)
+            assert x2.data_ptr() == xd.data_ptr()
+        else:
+            y, x2 = ops.layer_norm_gather(xd, gd, bd, 1e-5, wmap, inv, torch.bfloat16), xd
+        gy = det_uniform(tuple(y.shape), "lnp:gy").to(DEV)
+        ((y.float() * gy).sum() + (x2 * gx).sum()).backward()
+        res.append((y.detach(), xd.grad, gd.grad, bd.grad))
+    for a, b in zip(res[0], res[1]):
+        assert torch.allclose(a.float(), b.float(), rtol=1e-6, atol=1e-6)
+    # only the shortcut used downstream
+    xd = x.to(DEV).requires_grad_(True)
+    y, x2 = ops.layer_norm_gather(xd, gamma.to(DEV), beta.to(DEV), 1e-5, wmap, inv, torch.bfloat16, passthrough=True)
+    (x2 * gx).sum().backward()
+    assert torch.equal(xd.grad, gx)
+
+
 @pytest.mark.parametrize("H,W,C", [(5, 7, 32), (16, 32, 96), (8, 16, 384), (13, 25, 192)])
 @pytest.mark.parametrize("ydt", [torch.float32, torch.bfloat16])
 def test_layer_norm_patch_merge(ops, H, W, C, ydt):
