@@ -105,13 +105,15 @@ int pswin_haversine_windows(const float* uv1, const float* uv2, int n_windows, f
 int pswin_window_gather(const void* x, int x_dtype, const int32_t* map, const float* scale, void* win,
                         int win_dtype, int B, int S, int n_slots, int C, void* stream);
 
-/* out[b][t][:] = (resid ? resid[b][t][:] : 0) + (scale ? scale[b] : 1) * win[b][inv[t]][:]
+/* out[b][t][:] = (resid ? resid[b][t][:] : 0) + (scale ? scale[b] : 1) * (win[b][inv[t]][:] + (bias ? bias[:] : 0))
  * window_reverse + crop + reverse transition + residual add + DropPath scaling (HOT:483, 516-533), and,
- * with resid = NULL, backward of pswin_window_gather.
+ * with resid = NULL, backward of pswin_window_gather.  bias (f32 [C], may be NULL): the bias of the Linear that
+ * produced win (proj, HOT:309; fc2, HOT:58), added here so that the GEMM runs without an epilogue and the bias
+ * gradient comes out of pswin_ln_gather_bwd (dres_sum) instead of a column-sum pass over the GEMM's output gradient.
  * win: [B, n_slots, C] win_dtype; resid, out: [B, S, C] of x_dtype. */
 int pswin_window_scatter_add(const void* win, int win_dtype, const int32_t* inv, const void* resid,
-                             const float* scale, void* out, int x_dtype, int B, int S, int n_slots, int C,
-                             void* stream);
+                             const float* scale, const float* bias, void* out, int x_dtype, int B, int S, int n_slots,
+                             int C, void* stream);
 
 /* LayerNorm fused into the window gather: y[b][slot][:] = LN(x[b][map[slot]][:]) * gamma + beta, zero rows in the
  * padding slots (the reference pads AFTER norm1: HOT:504, 512).  Replaces norm1 + WindowTransition + pad_x +
@@ -127,10 +129,14 @@ int pswin_ln_gather_fwd(const void* x, int x_dtype, const int32_t* map, const fl
  *   dgamma = sum dy * xhat, dbeta = sum dy (block partials in `workspace`, reduced in a fixed order).
  * dres (may be NULL; f32 [B, S, C], needs x_dtype f32): the gradient reaching x along the residual shortcut
  * (x + DropPath(f(norm(x))), HOT:533-536); it is added into dx here, which replaces autograd's separate accumulation pass.
+ * dres_sum (may be NULL; f32 [C]) = sum_{b,t} res_scale[b] * dres[b][t][:] (res_scale: f32 [B] DropPath factors or NULL = 1):
+ * the gradient of a bias that pswin_window_scatter_add added on the branch whose shortcut dres came along (the proj /
+ * fc2 bias of the block, HOT:309, 58), obtained from the pass that reads dres anyway.
  * dy: [B, n_out, C] dy_dtype; dx: [B, S, C] x_dtype; workspace: f32, pswin_ln_workspace(B * S, C) elements. */
 int pswin_ln_gather_bwd(const void* dy, int dy_dtype, const int32_t* inv, const void* x, int x_dtype, const float* mean,
-                        const float* rstd, const float* gamma, const float* dres, void* dx, float* dgamma, float* dbeta,
-                        float* workspace, int B, int S, int n_out, int C, void* stream);
+                        const float* rstd, const float* gamma, const float* dres, const float* res_scale,
+                        float* dres_sum, void* dx, float* dgamma, float* dbeta, float* workspace, int B, int S, int n_out,
+                        int C, void* stream);
 
 /* Workspace elements for the LayerNorm backward kernels over `rows` walked rows of width C. */
 int pswin_ln_workspace(long long rows, int C);
@@ -221,6 +227,16 @@ int pswin_stem_conv2_wgrad(const void* x4, const void* w1p, const float* scale1,
                            int H, int W, float* dw2, float* workspace, void* stream);
 int pswin_stem_conv2_bwd(const void* x4, const void* w1p, const float* prm, const void* dy2, const void* w2t, int B, int H,
                          int W, float* out, float* workspace, void* stream);
+
+/* Bias + exact GELU between fc1 and fc2 of Mlp (HOT:44-61).  y: [M, N] pre-activation WITHOUT the bias (the GEMM runs
+ * without an epilogue), bias: f32 [N] or NULL, dtype f32 or bf16, N % 8 == 0.
+ *   fwd: h = gelu(y + bias)      bwd: dy = dh * gelu'(y + bias), dbias[n] = sum_m dy[m][n] (f32, fixed order)
+ * workspace: f32, pswin_bias_gelu_workspace(M, N) elements. */
+int pswin_bias_gelu_fwd(const void* y, int dtype, const float* bias, void* h, long long M, int N, void* stream);
+int pswin_bias_gelu_workspace(long long M, int N);
+int pswin_bias_gelu_tune(int unr_fwd, int unr_bwd);   /* rows steps per block of the two kernels: 1, 2 or 4 (default 2, 4) */
+int pswin_bias_gelu_bwd(const void* dh, const void* y, int dtype, const float* bias, void* dy, float* dbias,
+                        float* workspace, long long M, int N, void* stream);
 
 /* Column sums of a row-major [M, N] matrix in fp32: out[n] = sum_m x[m][n] (fixed summation order).  The bias
  * gradient of every Linear on the path (autograd of nn.Linear, HOT:50-52, 236, 323) and the reduction of split-K

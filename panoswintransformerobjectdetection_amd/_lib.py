@@ -27,9 +27,9 @@ _PROTOTYPES = {
     "pswin_gather_uv": [_vp, _vp, _i, _vp, _vp],
     "pswin_haversine_windows": [_vp, _vp, _i, _vp, _vp],
     "pswin_window_gather": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
-    "pswin_window_scatter_add": [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "pswin_window_scatter_add": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "pswin_ln_gather_fwd": [_vp, _i, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
-    "pswin_ln_gather_bwd": [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "pswin_ln_gather_bwd": [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "pswin_ln_workspace": [ctypes.c_longlong, _i],
     "pswin_ln_patch_merge_fwd": [_vp, _i, _vp, _vp, _f, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     "pswin_ln_patch_merge_bwd": [_vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
@@ -48,6 +48,10 @@ _PROTOTYPES = {
     "pswin_stem_conv3_wgrad": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
     "pswin_stem_conv2_wgrad": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
     "pswin_stem_conv2_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
+    "pswin_bias_gelu_fwd": [_vp, _i, _vp, _vp, ctypes.c_longlong, _i, _vp],
+    "pswin_bias_gelu_workspace": [ctypes.c_longlong, _i],
+    "pswin_bias_gelu_tune": [_i, _i],
+    "pswin_bias_gelu_bwd": [_vp, _vp, _i, _vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _vp],
     "pswin_colsum_workspace": [ctypes.c_longlong, _i, _i],
     "pswin_colsum": [_vp, _i, ctypes.c_longlong, _i, _vp, _vp, _vp],
     "pswin_interp_rows": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],

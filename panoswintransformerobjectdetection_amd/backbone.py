@@ -76,6 +76,10 @@ class Mlp(nn.Module):
     def forward(self, x, cd):
         return _linear(F.gelu(_linear(x, self.fc1, cd)), self.fc2, cd)
 
+    def forward_nobias2(self, x, cd):
+        """fc2(gelu(fc1 x + b1)) WITHOUT fc2's bias (the caller adds it with the residual): bias + GELU in one HIP pass"""
+        return _linear(ops.bias_gelu(_linear(x, self.fc1, cd, use_bias=False), self.fc1.bias), self.fc2, cd, use_bias=False)
+
 
 class WindowAttention(nn.Module, DoubleModeModule):
     """Parameter holder of BasicWindowAttention / WindowAttention (HOT:211-323)."""
@@ -140,15 +144,17 @@ class _LinearSplitK(torch.autograd.Function):
         return dx, dw, db, None, None
 
 
-def _linear(x, lin, cd):
-    """nn.Linear on rows.  fp32: F.linear (parity path).  bf16: split-K weight gradient, fp32 parameter gradients."""
+def _linear(x, lin, cd, use_bias=True):
+    """nn.Linear on rows.  fp32: F.linear (parity path).  bf16: split-K weight gradient, fp32 parameter gradients.
+    use_bias=False: the caller applies lin.bias itself (fused into the next row kernel)."""
     if cd == torch.float32:
-        return F.linear(x.float(), lin.weight, lin.bias)
+        return F.linear(x.float(), lin.weight, lin.bias if use_bias else None)
     shp = x.shape
     x2 = x.to(cd).reshape(-1, shp[-1])
     lp = lin.__dict__.get("_lowp")
     w_lp, b_lp = lp if lp is not None else (None, None)
-    return _LinearSplitK.apply(x2, lin.weight, lin.bias, w_lp, b_lp).view(*shp[:-1], lin.weight.shape[0])
+    bias = lin.bias if use_bias else None
+    return _LinearSplitK.apply(x2, lin.weight, bias, w_lp, b_lp if use_bias else None).view(*shp[:-1], lin.weight.shape[0])
 
 
 class PanoSwinTransformerBlock(nn.Module, DoubleModeModule):
@@ -165,7 +171,9 @@ class PanoSwinTransformerBlock(nn.Module, DoubleModeModule):
         self.mlp = Mlp(dim, int(dim * mlp_ratio))
         self.pano_mode = pano_mode
 
-    def forward(self, x, H, W, cd):
+    def forward(self, x, H, W, cd, dp_scales=None):
+        """dp_scales: this block's two DropPath factor vectors ([2, B], from one batched draw for the whole network, see
+        SimplePanoSwinTransformer.forward) or None: draw them here."""
         B, S, C = x.shape
         assert S == H * W, "input feature has wrong size"
         dev = x.device
@@ -178,19 +186,28 @@ class PanoSwinTransformerBlock(nn.Module, DoubleModeModule):
             mask = ops.planar_mask_tiles(H, W, self.shift_size, dev) if self.shift_size else None   # HOT:474
         a = self.attn
         n1 = self.norm1                                                           # norm1 + shift + pad + partition
+        # bf16 path: the proj / fc2 biases ride on the residual row kernels and fc1's on the GELU kernel (no GEMM
+        # epilogues, no column-sum passes for their gradients); fp32 (parity) path: plain F.linear with bias
+        fuse = cd != torch.float32
+        if dp_scales is not None and self.drop_path_p > 0.0 and self.training:
+            s1, s2 = dp_scales[0], dp_scales[1]
+        else:
+            s1 = _drop_path_scale(x, self.drop_path_p, self.training)             # HOT:533: one draw per branch
+            s2 = _drop_path_scale(x, self.drop_path_p, self.training)             # HOT:536
         # the second result is x itself: using it for the shortcut folds the shortcut's gradient into the LN backward kernel
-        win, x = ops.layer_norm_gather(x, n1.weight, n1.bias, n1.eps, wmap, inv, cd, passthrough=True)  # [B, nW*49, C]
+        win, x = ops.layer_norm_gather(x, n1.weight, n1.bias, n1.eps, wmap, inv, cd, passthrough=True,
+                                       res_bias=a.proj.bias if fuse else None, res_scale=s1)   # [B, nW*49, C]
         qkv = _linear(win.view(-1, C), a.qkv, cd)                                 # [B*nW*49, 3C]
         att = ops.window_attention(qkv, a.sphere_position_alpha_table_Te, a.sphere_position_beta_table_Te, dist, mask,
                                    a.num_heads, a.scale, nW)
-        att = _linear(att, a.proj, cd).view(B, nW * WTOK, C)
-        scale = _drop_path_scale(x, self.drop_path_p, self.training)
-        x = ops.window_scatter_add(att, x, wmap, inv, scale)                      # shortcut + DropPath(attn)
+        att = _linear(att, a.proj, cd, use_bias=not fuse).view(B, nW * WTOK, C)
+        x = ops.window_scatter_add(att, x, wmap, inv, s1, a.proj.bias if fuse else None, True)   # shortcut + DropPath(attn)
         n2 = self.norm2
-        h, x = ops.layer_norm_gather(x, n2.weight, n2.bias, n2.eps, out_dtype=cd, passthrough=True)
-        y = self.mlp(h, cd)
+        h, x = ops.layer_norm_gather(x, n2.weight, n2.bias, n2.eps, out_dtype=cd, passthrough=True,
+                                     res_bias=self.mlp.fc2.bias if fuse else None, res_scale=s2)
+        y = self.mlp.forward_nobias2(h, cd) if fuse else self.mlp(h, cd)
         ident = ops.identity_map(S, dev)                                          # x + DropPath(mlp): one row kernel
-        return ops.window_scatter_add(y, x, ident, ident, scale)
+        return ops.window_scatter_add(y, x, ident, ident, s2, self.mlp.fc2.bias if fuse else None, True)
 
 
 class PitchAttentionModule(WindowAttention):
@@ -290,13 +307,16 @@ class BasicLayer(nn.Module, DoubleModeModule):
         for blk in self.blocks:
             blk.set_pano_mode(pano_mode)
 
-    def forward(self, x, H, W, cd, out_norm=None):
+    def forward(self, x, H, W, cd, out_norm=None, dp_scales=None):
         """-> (stage output [normed by out_norm if given], H, W, input of the next stage, its H, W)"""
-        for blk in self.blocks:
+        for i, blk in enumerate(self.blocks):
+            extra = ()
+            if dp_scales is not None and isinstance(blk, PanoSwinTransformerBlock):
+                extra = (dp_scales[i],)
             if self.use_checkpoint:
-                x = checkpoint.checkpoint(blk, x, H, W, cd, use_reentrant=False)
+                x = checkpoint.checkpoint(blk, x, H, W, cd, *extra, use_reentrant=False)
             else:
-                x = blk(x, H, W, cd)
+                x = blk(x, H, W, cd, *extra)
         y = x
         if out_norm is not None:                    # output norm first: the downsample branch's gradient then joins
             if self.downsample is not None:         # the stream inside the norm's backward kernel
@@ -483,12 +503,37 @@ class SimplePanoSwinTransformer(nn.Module, DoubleModeModule):
             feat = ops.abs_pos_features(Wh, Ww, x.device)                               # HOT:926-934
             x = x + F.linear(feat, self.abs_encoder.weight, self.abs_encoder.bias)[None]
         outs = []
+        dp_all = self._draw_drop_path(x) if self.training else None
         for i, layer in enumerate(self.layers):
             nl = getattr(self, f"norm{i}") if i in self.out_indices else None
-            y, H, W, x, Wh, Ww = layer(x, Wh, Ww, cd, nl)
+            y, H, W, x, Wh, Ww = layer(x, Wh, Ww, cd, nl, None if dp_all is None else dp_all[i])
             if nl is not None:
                 outs.append(y.view(-1, H, W, self.num_features[i]).permute(0, 3, 1, 2).contiguous())
         return tuple(outs)
+
+    def _draw_drop_path(self, x):
+        """All DropPath factors of one forward pass from ONE uniform draw (two per block: HOT:533, 536): per stage a
+        [blocks, 2, B] tensor of floor(keep + U) / keep.  The reference draws per call; drawing up front gives the same
+        distribution with 4 small kernels per step instead of 3 per branch."""
+        keeps = []
+        for layer in self.layers:
+            for blk in layer.blocks:
+                p = getattr(blk, "drop_path_p", 0.0)
+                keeps += [1.0 - p, 1.0 - p]
+        if not any(k < 1.0 for k in keeps):
+            return None
+        key = (x.device, tuple(keeps))
+        if getattr(self, "_dp_keep_key", None) != key:
+            self._dp_keep = torch.tensor(keeps, dtype=torch.float32, device=x.device)[:, None]
+            self._dp_keep_key = key
+        u = torch.rand(len(keeps), x.shape[0], dtype=torch.float32, device=x.device)
+        scales = torch.floor(self._dp_keep + u) / self._dp_keep
+        out, at = [], 0
+        for layer in self.layers:
+            n = len(layer.blocks)
+            out.append(scales[at:at + 2 * n].view(n, 2, -1))
+            at += 2 * n
+        return out
 
     def train(self, mode=True):
         """The reference's train() forgets to return self (HOT:981-983); nn.Module semantics are kept here."""

@@ -58,7 +58,8 @@ __global__ void window_gather_kernel(const void* __restrict__ x, const int32_t* 
 template <int WDT, int XDT>
 __global__ void window_scatter_add_kernel(const void* __restrict__ win, const int32_t* __restrict__ inv,
                                           const void* __restrict__ resid, const float* __restrict__ scale,
-                                          void* __restrict__ out, long long rows, int S, int n_slots, int vpr) {
+                                          const float* __restrict__ bias, void* __restrict__ out, long long rows, int S,
+                                          int n_slots, int vpr) {
     long long row = (long long)blockIdx.x * blockDim.y + threadIdx.y;
     if (row >= rows) return;
     int b = (int)(row / S);
@@ -68,6 +69,7 @@ __global__ void window_scatter_add_kernel(const void* __restrict__ win, const in
     size_t C = (size_t)vpr * 4;
     for (int v = threadIdx.x; v < vpr; v += blockDim.x) {
         f32x4 val = load4<WDT>(win, ((size_t)b * n_slots + slot) * C + 4 * (size_t)v);
+        if (bias) val = val + *reinterpret_cast<const f32x4*>(bias + 4 * (size_t)v);
         if (scale) val = val * sc;
         if (resid) val = val + load4<XDT>(resid, (size_t)row * C + 4 * (size_t)v);
         store4<XDT>(out, (size_t)row * C + 4 * (size_t)v, val);
@@ -184,18 +186,18 @@ extern "C" int pswin_window_gather(const void* x, int x_dtype, const int32_t* ma
 }
 
 extern "C" int pswin_window_scatter_add(const void* win, int win_dtype, const int32_t* inv, const void* resid,
-                                        const float* scale, void* out, int x_dtype, int B, int S, int n_slots, int C,
-                                        void* stream) {
+                                        const float* scale, const float* bias, void* out, int x_dtype, int B, int S,
+                                        int n_slots, int C, void* stream) {
     PSWIN_CHECK_ARG(win && inv && out && B > 0 && S > 0 && n_slots > 0 && C > 0);
     PSWIN_CHECK_ARG(valid_dtype(x_dtype) && valid_dtype(win_dtype));
-    PSWIN_CHECK_ARG(C % 8 == 0 && aligned16(win) && aligned16(out) && aligned16(resid));
+    PSWIN_CHECK_ARG(C % 8 == 0 && aligned16(win) && aligned16(out) && aligned16(resid) && aligned16(bias));
     RowGeom g = row_geom(C);
     long long rows = (long long)B * S;
     PSWIN_CHECK_ARG(rows_ok(rows, g.rows_per_block));
     dim3 grid((unsigned)((rows + g.rows_per_block - 1) / g.rows_per_block));
     return dispatch2(win_dtype, x_dtype, [&](auto wd, auto xd) {
         hipLaunchKernelGGL((window_scatter_add_kernel<decltype(wd)::value, decltype(xd)::value>), grid, g.block, 0,
-                           (hipStream_t)stream, win, inv, resid, scale, out, rows, S, n_slots, g.vpr);
+                           (hipStream_t)stream, win, inv, resid, scale, bias, out, rows, S, n_slots, g.vpr);
         PSWIN_LAUNCH_RET();
     });
 }

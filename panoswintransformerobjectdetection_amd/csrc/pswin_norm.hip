@@ -117,23 +117,29 @@ __global__ __launch_bounds__(THREADS) void ln_fwd_kernel(const void* __restrict_
 
 // Backward.  MODE 0 walks source tokens (b, t): dy row = dy[b][inv ? inv[t] : t].  MODE 1 walks merged rows and
 // scatters the 4 quarters of dx back to their tokens.  dgamma / dbeta: per-block partial sums, fixed order.
-template <int MODE, int DYDT, int XDT, int L, int NCH>
+// RSUM: also accumulate sum_rows res_scale[b] * dres[row] (the bias gradient of the Linear whose output, plus bias, was
+// added onto the residual stream through the shortcut this LayerNorm's input came along): third partial segment.
+template <int MODE, int DYDT, int XDT, int L, int NCH, bool RSUM>
 __global__ __launch_bounds__(THREADS) void ln_bwd_kernel(const void* __restrict__ dy, const int32_t* __restrict__ inv,
                                                          const void* __restrict__ x, RowSrc rs,
                                                          const float* __restrict__ mean,
                                                          const float* __restrict__ rstd,
                                                          const float* __restrict__ gamma, void* __restrict__ dx,
-                                                         const float* __restrict__ dres, float* __restrict__ part,
+                                                         const float* __restrict__ dres,
+                                                         const float* __restrict__ res_scale, float* __restrict__ part,
                                                          long long rows, int C) {
     constexpr int RPB = THREADS / L;
+    constexpr int NSEG = RSUM ? 3 : 2;
     __shared__ float red[2][THREADS * 4];      // [row group][lane][4 elements] of one chunk column at a time
     const int lane = threadIdx.x % L;
     const int rsub = threadIdx.x / L;
     const int nchunks = C / 4;
     const int n_in = (MODE == 0) ? rs.S : rs.n_out;        // rows walked per image
-    f32x4 dg[NCH], db[NCH];
+    f32x4 dg[NCH], db[NCH], dr[RSUM ? NCH : 1];
 #pragma unroll
     for (int k = 0; k < NCH; ++k) dg[k] = db[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < (RSUM ? NCH : 1); ++k) dr[k] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (long long row = (long long)blockIdx.x * RPB + rsub; row < rows; row += (long long)gridDim.x * RPB) {
         const int b = (int)(row / n_in);
         const int r = (int)(row - (long long)b * n_in);
@@ -142,6 +148,7 @@ __global__ __launch_bounds__(THREADS) void ln_bwd_kernel(const void* __restrict_
         else dy_row = (size_t)row;
         const size_t img_in = (size_t)b * rs.S * (MODE == 0 ? C : C / 4);
         const float mu = mean[row], rs_ = rstd[row];
+        const float rsc = (RSUM && res_scale) ? res_scale[b] : 1.0f;
         f32x4 xh[NCH], g[NCH];
         long long offs[NCH];
         float s1 = 0.f, s2 = 0.f;
@@ -172,13 +179,17 @@ __global__ __launch_bounds__(THREADS) void ln_bwd_kernel(const void* __restrict_
             if (ch < nchunks && offs[k] >= 0) {
                 f32x4 v = (g[k] - s1 - xh[k] * s2) * rs_;
                 // the gradient that reaches x along the residual shortcut, added here instead of in a separate pass
-                if (dres) v = v + *reinterpret_cast<const f32x4*>(dres + img_in + (size_t)offs[k]);
+                if (dres) {
+                    const f32x4 rv = *reinterpret_cast<const f32x4*>(dres + img_in + (size_t)offs[k]);
+                    v = v + rv;
+                    if constexpr (RSUM) dr[k] = dr[k] + rv * rsc;
+                }
                 store4<XDT>(dx, img_in + (size_t)offs[k], v);
             }
         }
     }
     // block reduction of dgamma / dbeta over the RPB row groups (fixed order), then one partial row per block
-    float* outp = part + (size_t)blockIdx.x * 2 * C;
+    float* outp = part + (size_t)blockIdx.x * NSEG * C;
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
         const int ch = lane + k * L;
@@ -195,6 +206,7 @@ __global__ __launch_bounds__(THREADS) void ln_bwd_kernel(const void* __restrict_
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float a = 0.f, c = 0.f;
+#pragma unroll 4
                 for (int q = 0; q < RPB; ++q) {
                     a += red[0][(q * L + lane) * 4 + e];
                     c += red[1][(q * L + lane) * 4 + e];
@@ -203,16 +215,33 @@ __global__ __launch_bounds__(THREADS) void ln_bwd_kernel(const void* __restrict_
                 outp[C + 4 * ch + e] = c;
             }
         }
+        if constexpr (RSUM) {
+            __syncthreads();
+            if (ch < nchunks) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) red[0][(rsub * L + lane) * 4 + e] = dr[k][e];
+            }
+            __syncthreads();
+            if (rsub == 0 && ch < nchunks) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float a = 0.f;
+#pragma unroll 4
+                    for (int q = 0; q < RPB; ++q) a += red[0][(q * L + lane) * 4 + e];
+                    outp[2 * C + 4 * ch + e] = a;
+                }
+            }
+        }
     }
 }
 
-// out_a[c] = sum_r part[r][c], out_b[c] = sum_r part[r][C + c]  (rows of 2C floats); 16 columns x 64 row lanes
-__global__ void colsum2_kernel(const float* __restrict__ part, int R, int C, float* __restrict__ out_a,
-                               float* __restrict__ out_b) {
+// out_k[c] = sum_r part[r][k * C + c] for the nseg (2 or 3) segments of rows of nseg * C floats; 16 columns x 64 row lanes
+__global__ void colsum_seg_kernel(const float* __restrict__ part, int R, int C, int nseg, float* __restrict__ out_a,
+                                  float* __restrict__ out_b, float* __restrict__ out_c) {
     __shared__ float red[64][16];
     const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cl;
-    const int N = 2 * C;
+    const int N = nseg * C;
     float s0 = 0.f, s1 = 0.f;
     if (c < N) {
         int r = rl;
@@ -231,12 +260,14 @@ __global__ void colsum2_kernel(const float* __restrict__ part, int R, int C, flo
 #pragma unroll
         for (int k = 0; k < 16; ++k) s += red[k][cl];
         if (c < C) out_a[c] = s;
-        else out_b[c - C] = s;
+        else if (c < 2 * C) out_b[c - C] = s;
+        else out_c[c - 2 * C] = s;
     }
 }
 
-inline void launch_colsum_2(const float* part, int R, int C, float* out_a, float* out_b, hipStream_t st) {
-    hipLaunchKernelGGL(colsum2_kernel, dim3((2 * C + 15) / 16), dim3(1024), 0, st, part, R, C, out_a, out_b);
+inline void launch_colsum_seg(const float* part, int R, int C, int nseg, float* out_a, float* out_b, float* out_c,
+                              hipStream_t st) {
+    hipLaunchKernelGGL(colsum_seg_kernel, dim3((nseg * C + 15) / 16), dim3(1024), 0, st, part, R, C, nseg, out_a, out_b, out_c);
 }
 
 // up to 4 chunks of 4 elements per lane (8 for rows wider than 1024 elements: PatchMerging of C >= 384)
@@ -279,18 +310,18 @@ int launch_fwd(int L, const void* x, const RowSrc& rs, const float* gamma, const
     PSWIN_LAUNCH_RET();
 }
 
-template <int MODE, int DYDT, int XDT>
+template <int MODE, int DYDT, int XDT, bool RSUM>
 int launch_bwd(int L, const void* dy, const int32_t* inv, const void* x, const RowSrc& rs, const float* mean,
-               const float* rstd, const float* gamma, void* dx, const float* dres, float* part, long long rows, int C,
-               int blocks, hipStream_t st) {
-#define PSWIN_LN_BWD(LL)                                                                                          \
-    case LL:                                                                                                      \
-        hipLaunchKernelGGL((ln_bwd_kernel<MODE, DYDT, XDT, LL, 4>), dim3(blocks), dim3(THREADS), 0, st, dy, inv, \
-                           x, rs, mean, rstd, gamma, dx, dres, part, rows, C);                                    \
+               const float* rstd, const float* gamma, void* dx, const float* dres, const float* res_scale, float* part,
+               long long rows, int C, int blocks, hipStream_t st) {
+#define PSWIN_LN_BWD(LL)                                                                                                \
+    case LL:                                                                                                            \
+        hipLaunchKernelGGL((ln_bwd_kernel<MODE, DYDT, XDT, LL, 4, RSUM>), dim3(blocks), dim3(THREADS), 0, st, dy, inv, \
+                           x, rs, mean, rstd, gamma, dx, dres, res_scale, part, rows, C);                               \
         break;
     if (wide_row(C)) {
-        hipLaunchKernelGGL((ln_bwd_kernel<MODE, DYDT, XDT, 64, 8>), dim3(blocks), dim3(THREADS), 0, st, dy, inv, x, rs,
-                           mean, rstd, gamma, dx, dres, part, rows, C);
+        hipLaunchKernelGGL((ln_bwd_kernel<MODE, DYDT, XDT, 64, 8, RSUM>), dim3(blocks), dim3(THREADS), 0, st, dy, inv, x, rs,
+                           mean, rstd, gamma, dx, dres, res_scale, part, rows, C);
         PSWIN_LAUNCH_RET();
     }
     switch (L) {
@@ -313,7 +344,7 @@ inline int dispatch2(int a, int b, F&& f) {
 
 extern "C" int pswin_ln_workspace(long long rows, int C) {
     if (rows <= 0 || C <= 0 || C % 8) return PSWIN_ERR_ARG;
-    return bwd_blocks(rows, pick_lanes(C)) * 2 * C;
+    return bwd_blocks(rows, pick_lanes(C)) * 3 * C;
 }
 
 extern "C" int pswin_ln_gather_fwd(const void* x, int x_dtype, const int32_t* map, const float* gamma,
@@ -334,24 +365,34 @@ extern "C" int pswin_ln_gather_fwd(const void* x, int x_dtype, const int32_t* ma
 
 extern "C" int pswin_ln_gather_bwd(const void* dy, int dy_dtype, const int32_t* inv, const void* x, int x_dtype,
                                    const float* mean, const float* rstd, const float* gamma, const float* dres,
-                                   void* dx, float* dgamma, float* dbeta, float* workspace, int B, int S, int n_out,
-                                   int C, void* stream) {
+                                   const float* res_scale, float* dres_sum, void* dx, float* dgamma, float* dbeta,
+                                   float* workspace, int B, int S, int n_out, int C, void* stream) {
     PSWIN_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && workspace && B > 0 && S > 0 && n_out > 0);
     PSWIN_CHECK_ARG(valid_dtype(x_dtype) && valid_dtype(dy_dtype));
     PSWIN_CHECK_ARG(C >= 8 && C % 8 == 0 && C <= MAX_C && aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(gamma));
     PSWIN_CHECK_ARG(inv || n_out == S);
     PSWIN_CHECK_ARG(!dres || (x_dtype == PSWIN_F32 && aligned16(dres)));
+    PSWIN_CHECK_ARG(!dres_sum || dres);
     RowSrc rs = {0, nullptr, S, n_out, 0, 0, 0};
     const long long rows = (long long)B * S;
     const int L = pick_lanes(C);
     const int blocks = bwd_blocks(rows, L);
-    int rc = dispatch2(dy_dtype, x_dtype, [&](auto dd, auto xd) {
-        return launch_bwd<0, decltype(dd)::value, decltype(xd)::value>(L, dy, inv, x, rs, mean, rstd, gamma, dx, dres,
+    int rc;
+    if (dres_sum) {
+        rc = dispatch2(dy_dtype, PSWIN_F32, [&](auto dd, auto xd) {
+            return launch_bwd<0, decltype(dd)::value, PSWIN_F32, true>(L, dy, inv, x, rs, mean, rstd, gamma, dx, dres, res_scale,
                                                                        workspace, rows, C, blocks, (hipStream_t)stream);
-    });
+        });
+    } else {
+        rc = dispatch2(dy_dtype, x_dtype, [&](auto dd, auto xd) {
+            return launch_bwd<0, decltype(dd)::value, decltype(xd)::value, false>(L, dy, inv, x, rs, mean, rstd, gamma, dx, dres,
+                                                                                  nullptr, workspace, rows, C, blocks,
+                                                                                  (hipStream_t)stream);
+        });
+    }
     if (rc) return rc;
-    // partial rows are [dgamma(C) | dbeta(C)]; the two outputs may live in different buffers -> two column sums
-    launch_colsum_2(workspace, blocks, C, dgamma, dbeta, (hipStream_t)stream);
+    // partial rows are [dgamma(C) | dbeta(C) | dres_sum(C)]; the outputs may live in different buffers
+    launch_colsum_seg(workspace, blocks, C, dres_sum ? 3 : 2, dgamma, dbeta, dres_sum, (hipStream_t)stream);
     PSWIN_LAUNCH_RET();
 }
 
@@ -385,11 +426,11 @@ extern "C" int pswin_ln_patch_merge_bwd(const void* dy, int dy_dtype, const void
     const int L = pick_lanes(C4);
     const int blocks = bwd_blocks(rows, L);
     int rc = dispatch2(dy_dtype, x_dtype, [&](auto dd, auto xd) {
-        return launch_bwd<1, decltype(dd)::value, decltype(xd)::value>(L, dy, nullptr, x, rs, mean, rstd, gamma, dx,
-                                                                       nullptr, workspace, rows, C4, blocks,
-                                                                       (hipStream_t)stream);
+        return launch_bwd<1, decltype(dd)::value, decltype(xd)::value, false>(L, dy, nullptr, x, rs, mean, rstd, gamma, dx,
+                                                                              nullptr, nullptr, workspace, rows, C4, blocks,
+                                                                              (hipStream_t)stream);
     });
     if (rc) return rc;
-    launch_colsum_2(workspace, blocks, C4, dgamma, dbeta, (hipStream_t)stream);
+    launch_colsum_seg(workspace, blocks, C4, 2, dgamma, dbeta, nullptr, (hipStream_t)stream);
     PSWIN_LAUNCH_RET();
 }

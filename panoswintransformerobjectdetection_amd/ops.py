@@ -117,10 +117,10 @@ def _gather_raw(x, wmap, scale, n_slots, out_dtype):
     return win
 
 
-def _scatter_raw(win, inv, resid, scale, S, out_dtype):
+def _scatter_raw(win, inv, resid, scale, S, out_dtype, bias=None):
     B, n_slots, C = win.shape
     out = torch.empty(B, S, C, dtype=out_dtype, device=win.device)
-    call("pswin_window_scatter_add", win, ptr(win), dtype_code(win), ptr(inv), ptr(resid), ptr(scale), ptr(out),
+    call("pswin_window_scatter_add", win, ptr(win), dtype_code(win), ptr(inv), ptr(resid), ptr(scale), ptr(bias), ptr(out),
          dtype_code(out), B, S, n_slots, C,
          algo_bytes=B * S * C * (win.element_size() + out.element_size() * (1 if resid is None else 2)))
     return out
@@ -146,23 +146,33 @@ def window_gather(x, wmap, inv, out_dtype=None):
 
 class _WindowScatterAdd(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, win, resid, wmap, inv, scale):
+    def forward(ctx, win, resid, wmap, inv, scale, bias, bias_grad_elsewhere):
         ctx.save_for_backward(wmap, scale)
         ctx.win_dtype = win.dtype
-        return _scatter_raw(win.contiguous(), inv, resid.contiguous(), scale, resid.shape[1], resid.dtype)
+        ctx.bias_grad = bias is not None and not bias_grad_elsewhere
+        b = None if bias is None else bias.detach().float().contiguous()
+        return _scatter_raw(win.contiguous(), inv, resid.contiguous(), scale, resid.shape[1], resid.dtype, b)
 
     @staticmethod
     def backward(ctx, dout):
         wmap, scale = ctx.saved_tensors
         dout = dout.contiguous()
         dwin = _gather_raw(dout, wmap, scale, wmap.numel(), ctx.win_dtype)
-        return dwin, dout, None, None, None
+        dbias = None
+        if ctx.bias_grad and ctx.needs_input_grad[5]:       # generic path: one extra pass (the blocks avoid it, see below)
+            g = dout.float() if scale is None else dout.float() * scale[:, None, None]
+            dbias = colsum(g.reshape(-1, g.shape[-1]))
+        return dwin, dout, None, None, None, dbias, None
 
 
-def window_scatter_add(win, resid, wmap, inv, scale=None):
-    """resid + scale_b * window_reverse(win): window reverse + crop + reverse shift + DropPath + residual
-    (HOT:483, 516-533) in one indexed row copy.  win [B, nW*49, C], resid [B, S, C]."""
-    return _WindowScatterAdd.apply(win, resid, wmap, inv, scale)
+def window_scatter_add(win, resid, wmap, inv, scale=None, bias=None, bias_grad_elsewhere=False):
+    """resid + scale_b * (window_reverse(win) + bias): window reverse + crop + reverse shift + DropPath + residual
+    (HOT:483, 516-533) in one indexed row copy.  win [B, nW*49, C], resid [B, S, C].
+
+    bias: the bias of the Linear that produced win (so that the GEMM needs no epilogue).  bias_grad_elsewhere=True:
+    this op returns no gradient for it; the caller obtains it from layer_norm_gather(..., res_bias=bias), whose
+    backward kernel reads the shortcut gradient anyway."""
+    return _WindowScatterAdd.apply(win, resid, wmap, inv, scale, bias, bias_grad_elsewhere)
 
 
 class _PatchMergeGather(torch.autograd.Function):
@@ -192,7 +202,7 @@ def patch_merge_gather(x, H, W, out_dtype=None):
 
 class _LayerNormGather(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, wmap, inv, out_dtype, passthrough):
+    def forward(ctx, x, gamma, beta, eps, wmap, inv, out_dtype, passthrough, res_bias, res_scale):
         B, S, C = x.shape
         x = x.contiguous()
         n_out = S if wmap is None else wmap.numel()
@@ -202,40 +212,54 @@ class _LayerNormGather(torch.autograd.Function):
         call("pswin_ln_gather_fwd", x, ptr(x), dtype_code(x), ptr(wmap), ptr(gamma), ptr(beta), float(eps), ptr(y),
              dtype_code(y), ptr(mean), ptr(rstd), B, S, n_out, C,
              algo_bytes=B * C * (min(S, n_out) * x.element_size() + n_out * y.element_size()))
-        ctx.save_for_backward(x, gamma, mean, rstd, inv)
+        ctx.save_for_backward(x, gamma, mean, rstd, inv, res_scale)
         ctx.n_out = n_out
+        ctx.want_res_sum = res_bias is not None
         if passthrough:
             return y, x.view_as(x)
         return y
 
     @staticmethod
     def backward(ctx, dy, dres=None):
-        x, gamma, mean, rstd, inv = ctx.saved_tensors
+        x, gamma, mean, rstd, inv, res_scale = ctx.saved_tensors
         B, S, C = x.shape
         dx = torch.empty_like(x)
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
-        if dy is None:                                   # only the shortcut was used downstream
-            return dres, torch.zeros_like(gamma), torch.zeros_like(gamma), None, None, None, None, None
-        dy = dy.contiguous()
+        dres_sum = None
         if dres is not None:
             if x.dtype != torch.float32:
                 raise PswinError("the residual passthrough of layer_norm_gather needs an fp32 residual stream")
             dres = dres.float().contiguous()
+        if ctx.want_res_sum:
+            if dres is None:
+                raise PswinError("layer_norm_gather(res_bias=...) needs the passthrough output to be used as the shortcut")
+            dres_sum = torch.empty(C, dtype=torch.float32, device=x.device)
+        if dy is None:                                   # only the shortcut was used downstream
+            if dres_sum is not None:
+                g = dres if res_scale is None else dres * res_scale[:, None, None]
+                dres_sum = colsum(g.reshape(-1, C))
+            return dres, torch.zeros_like(gamma), torch.zeros_like(gamma), None, None, None, None, None, dres_sum, None
+        dy = dy.contiguous()
         ws = torch.empty(_lib.load().pswin_ln_workspace(B * S, C), dtype=torch.float32, device=x.device)
         call("pswin_ln_gather_bwd", x, ptr(dy), dtype_code(dy), ptr(inv), ptr(x), dtype_code(x), ptr(mean), ptr(rstd),
-             ptr(gamma), ptr(dres), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(ws), B, S, ctx.n_out, C,
-             algo_bytes=B * S * C * (dy.element_size() + (2 if dres is None else 3) * x.element_size()))
-        return dx, dgamma, dbeta, None, None, None, None, None
+             ptr(gamma), ptr(dres), ptr(res_scale), ptr(dres_sum), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(ws), B, S,
+             ctx.n_out, C, algo_bytes=B * S * C * (dy.element_size() + (2 if dres is None else 3) * x.element_size()))
+        return dx, dgamma, dbeta, None, None, None, None, None, dres_sum, None
 
 
-def layer_norm_gather(x, gamma, beta, eps, wmap=None, inv=None, out_dtype=None, passthrough=False):
+def layer_norm_gather(x, gamma, beta, eps, wmap=None, inv=None, out_dtype=None, passthrough=False, res_bias=None,
+                      res_scale=None):
     """LayerNorm over the last dim of x [B, S, C], written through a window map (norm1 + shift + pad + window
     partition, HOT:503-513) or in place order (wmap=None: norm2 / output norms).  Padding slots are zero rows.
 
     passthrough=True returns (y, x'): x' is x itself, to be used for the residual shortcut (x' + f(y)); the gradient
     that flows back into x' is then added to dx INSIDE the LayerNorm backward kernel instead of by a separate
-    accumulation pass over the residual stream (one per block half in the reference's autograd graph)."""
-    return _LayerNormGather.apply(x, gamma, beta, eps, wmap, inv, out_dtype or x.dtype, passthrough)
+    accumulation pass over the residual stream (one per block half in the reference's autograd graph).
+
+    res_bias (with passthrough): the bias b of the branch x' + scale_b * (f(y) + b) that window_scatter_add(...,
+    bias=b, bias_grad_elsewhere=True) adds; its gradient, sum_{b,t} res_scale[b] * grad(x')[b][t], is accumulated by
+    the same backward kernel (which reads grad(x') anyway) and returned here."""
+    return _LayerNormGather.apply(x, gamma, beta, eps, wmap, inv, out_dtype or x.dtype, passthrough, res_bias, res_scale)
 
 
 class _LayerNormPatchMerge(torch.autograd.Function):
@@ -331,6 +355,36 @@ def colsum(x2d):
     ws = torch.empty(_lib.load().pswin_colsum_workspace(M, N, dtype_code(x2d)), dtype=torch.float32, device=x2d.device)
     call("pswin_colsum", x2d, ptr(x2d), dtype_code(x2d), M, N, ptr(out), ptr(ws))
     return out
+
+
+class _BiasGelu(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, bias):
+        y = y.contiguous()
+        M, N = y.numel() // y.shape[-1], y.shape[-1]
+        h = torch.empty_like(y)
+        b = None if bias is None else bias.detach().float().contiguous()
+        call("pswin_bias_gelu_fwd", y, ptr(y), dtype_code(y), ptr(b), ptr(h), M, N, algo_bytes=2 * y.numel() * y.element_size())
+        ctx.save_for_backward(y, b)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        y, b = ctx.saved_tensors
+        M, N = y.numel() // y.shape[-1], y.shape[-1]
+        dh = dh.to(y.dtype).contiguous()
+        dy = torch.empty_like(y)
+        db = torch.empty(N, dtype=torch.float32, device=y.device)
+        ws = torch.empty(_lib.load().pswin_bias_gelu_workspace(M, N), dtype=torch.float32, device=y.device)
+        call("pswin_bias_gelu_bwd", y, ptr(dh), ptr(y), dtype_code(y), ptr(b), ptr(dy), ptr(db), ptr(ws), M, N,
+             algo_bytes=3 * y.numel() * y.element_size())
+        return dy, (db if b is not None else None)
+
+
+def bias_gelu(y, bias):
+    """gelu(y + bias) (exact, erf) on [..., N]; the backward pass also returns the bias gradient (column sums of
+    dy) from the same pass: fc1 bias + nn.GELU of Mlp (HOT:50-57) without a GEMM epilogue or a separate reduction."""
+    return _BiasGelu.apply(y, bias)
 
 
 class _InterpRows(torch.autograd.Function):

@@ -350,3 +350,56 @@ def test_rejects_cpu_and_bad_args(ops):
     with pytest.raises(PswinError):          # C not a multiple of 8
         ops.window_gather(torch.zeros(1, 49, 12, device=DEV), torch.zeros(49, dtype=torch.int32, device=DEV),
                           torch.zeros(49, dtype=torch.int32, device=DEV))
+
+
+@pytest.mark.parametrize("M,N,dt", [(300, 384, torch.bfloat16), (77, 3072, torch.bfloat16), (129, 96, torch.float32)])
+def test_bias_gelu(ops, M, N, dt):
+    """gelu(y + b) and its backward (dy, db) against torch's exact GELU on the same operands; bf16: one rounding of the
+    result (rtol 1e-2), the bias gradient is summed in f32 before rounding (compared with the f32 reference sum)."""
+    y = det_uniform((M, N), "bg:y", 3.0).to(dt)
+    b = det_uniform((N,), "bg:b", 0.5)
+    gh = det_uniform((M, N), "bg:g").to(dt)
+    yr, br = y.float().clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.gelu(yr + br)
+    (ref * gh.float()).sum().backward()
+    yd, bd = y.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    out = ops.bias_gelu(yd, bd)
+    out.backward(gh.to(DEV))
+    tol = dict(rtol=1e-5, atol=1e-6) if dt == torch.float32 else dict(rtol=1e-2, atol=1e-2)
+    assert torch.allclose(out.float().cpu(), ref, **tol)
+    assert torch.allclose(yd.grad.float().cpu(), yr.grad, **tol)
+    assert torch.allclose(bd.grad.cpu(), br.grad, rtol=1e-4, atol=1e-4 * br.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("use_scale", [False, True])
+def test_residual_bias_pair(ops, use_scale):
+    """x' + s_b (scatter(win) + bias) with the bias added by window_scatter_add and its gradient produced by the
+    LayerNorm backward kernel of the same residual branch (res_bias): equal to the plain autograd graph."""
+    B, H, W, C = 2, 13, 25, 96
+    x = det_uniform((B, H * W, C), "rb:x", 2.0)
+    gamma, beta, bias = det_uniform((C,), "rb:g", 0.5, 1.0), det_uniform((C,), "rb:b", 0.5), det_uniform((C,), "rb:bias", 0.5)
+    wmap, inv, nW = ops.window_maps(True, H, W, 3, DEV)
+    scale = torch.tensor([0.0, 1.25], device=DEV) if use_scale else None
+    gout = det_uniform((B, H * W, C), "rb:go").to(DEV)
+    wlin = det_uniform((C, C), "rb:w", 0.1).to(DEV)
+    res = []
+    for fused in (False, True):
+        xd = x.to(DEV).requires_grad_(True)
+        gd, bd, biasd = [t.to(DEV).requires_grad_(True) for t in (gamma, beta, bias)]
+        if fused:
+            y, x2 = ops.layer_norm_gather(xd, gd, bd, 1e-5, wmap, inv, torch.float32, passthrough=True, res_bias=biasd,
+                                          res_scale=scale)
+            out = ops.window_scatter_add(y @ wlin, x2, wmap, inv, scale, biasd, True)
+        else:
+            y = ops.layer_norm_gather(xd, gd, bd, 1e-5, wmap, inv, torch.float32)
+            out = ops.window_scatter_add(y @ wlin + biasd, xd, wmap, inv, scale)
+        (out * gout).sum().backward()
+        res.append((out.detach(), xd.grad, gd.grad, bd.grad, biasd.grad))
+    for a, b in zip(res[0], res[1]):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-5 * max(1.0, float(b.abs().max())))
+    # generic path: the scatter op itself returns the bias gradient when nobody else does
+    xd, biasd = x.to(DEV).requires_grad_(True), bias.to(DEV).requires_grad_(True)
+    win = ops.window_gather(xd, wmap, inv, torch.float32)
+    out = ops.window_scatter_add(win, xd, wmap, inv, scale, biasd)
+    (out * gout).sum().backward()
+    assert torch.allclose(biasd.grad, res[0][4], rtol=1e-5, atol=1e-4)
