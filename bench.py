@@ -110,10 +110,20 @@ def main():
     torch.manual_seed(1234 + rank)               # every rank its own shard of synthetic panoramas
     x = torch.randn(args.batch, 3, args.height, 2 * args.height, device=dev)
 
+    # Synthetic objective: a fixed random linear functional of the four feature maps (what a detection head's
+    # gradient looks like to the backbone: dense, zero-mean, O(1/numel)).  The mean of the LayerNorm-ed outputs used in
+    # earlier rounds is ~0 with a degenerate gradient, and torch's two-pass global reductions of graph-pool tensors
+    # return stale values from the second hipGraph replay on (ROCm 7.0 / torch 2.10: tools/dbg_graph3.py); a dot
+    # product is a single-pass GEMV and replays bit-exactly (tools/dbg_graph6.py checks every gradient against eager).
+    with torch.no_grad():
+        loss_w = [torch.randn_like(o).flatten() / o.numel() for o in model(x)]
+    for p in model.parameters():
+        p.grad = None
+
     def fwd_bwd():
         reducer.zero_grad()
         outs = model(x)
-        loss = sum(o.float().mean() for o in outs)
+        loss = sum(o.float().flatten() @ w for o, w in zip(outs, loss_w))
         loss.backward()
         if reducer.pack:
             reducer.pack_grads()

@@ -214,6 +214,8 @@ int pswin_stem_conv3_fwd(const void* y2, const float* scale2, const float* shift
  * conv3_wgrad: dw3 f32 [4 ky][8 waves][12][256] accumulator tiles (decoded by the host: stem.decode_dw3) of
  *   sum_tokens dtok (x) relu(scale2 y2 + shift2) patches.
  * conv2_wgrad: dw2 f32 [2][36][256] accumulator tiles (stem.decode_dw2) of sum_p dy2[p] (x) a1[p + tap], a1 recomputed.
+ * perm (both; int32, may be NULL): where each accumulator element goes in the parameter layout ([96][64][4][4] /
+ *   [64][32][3][3]); with it the final column sum writes the gradient directly in nn.Conv2d's weight layout.
  * conv2_bwd: out f32 [64 + 32*48]: sum g1 (= dbeta1), sum g1 * yhat1 (= dgamma1), G[ch][slot] = sum_p g1[p][ch] xp[p][slot]
  *   with g1 = conv2 data gradient of dy2 masked by relu(bn1 y1) > 0, never stored.  prm: f32 [4][32] = scale1, shift1,
  *   a = rstd1, b = -mean1 rstd1. */
@@ -222,9 +224,9 @@ int pswin_stem_conv3_bwd_stats(const void* dtok, const void* y2, const float* pr
 int pswin_stem_conv3_bwd_data(const void* dtok, const void* y2, const float* prm, const void* w3t, int B, int H, int W,
                               void* dy2, void* stream);
 int pswin_stem_conv3_wgrad(const void* dtok, const void* y2, const float* scale2, const float* shift2, int B, int H, int W,
-                           float* dw3, float* workspace, void* stream);
+                           const int32_t* perm, float* dw3, float* workspace, void* stream);
 int pswin_stem_conv2_wgrad(const void* x4, const void* w1p, const float* scale1, const float* shift1, const void* dy2, int B,
-                           int H, int W, float* dw2, float* workspace, void* stream);
+                           int H, int W, const int32_t* perm, float* dw2, float* workspace, void* stream);
 int pswin_stem_conv2_bwd(const void* x4, const void* w1p, const float* prm, const void* dy2, const void* w2t, int B, int H,
                          int W, float* out, float* workspace, void* stream);
 
@@ -237,6 +239,25 @@ int pswin_bias_gelu_workspace(long long M, int N);
 int pswin_bias_gelu_tune(int unr_fwd, int unr_bwd);   /* rows steps per block of the two kernels: 1, 2 or 4 (default 2, 4) */
 int pswin_bias_gelu_bwd(const void* dh, const void* y, int dtype, const float* bias, void* dy, float* dbias,
                         float* workspace, long long M, int N, void* stream);
+
+/* Small parameter kernels of the stem (one launch each).
+ * pack_weights: nn.Conv2d weights f32 ([32,3,3,3], [64,32,3,3], [96,64,4,4]) -> w1p, w2p, w2t, w3p, w3t (bf16).
+ * bn_fold: per-channel sum / sum of squares over `count` values of a bias-free convolution output -> prm f32 [4][C] =
+ *   scale, shift, rstd, -mean * rstd (z = scale y + shift, yhat = rstd y - mean rstd); training != 0: batch statistics
+ *   and nn.BatchNorm2d's running-statistics update (conv_bias, which cancels in z, is added to the tracked mean);
+ *   training == 0: running statistics (conv_bias subtracted from the mean).
+ * bn2_coefs: sums f32 [2][64] of conv3_bwd_stats + prm [4][64] -> prm5 f32 [5][64] = scale, shift, k1, P, Q for
+ *   conv3_bwd_data (P = Q = 0 when training == 0).
+ * conv1_wgrad: out5 of conv2_bwd, XX of conv1_stats (training), w1p, prm1 [4][32] -> dw1 f32 [32][3][3][3] and db1
+ *   (zero in training: a bias in front of a BatchNorm has no gradient). */
+int pswin_stem_pack_weights(const float* w1, const float* w2, const float* w3, void* w1p, void* w2p, void* w2t, void* w3p,
+                            void* w3t, void* stream);
+int pswin_stem_bn_fold(const float* sum, const float* sumsq, double count, const float* gamma, const float* beta,
+                       const float* conv_bias, float eps, float momentum, int training, float* running_mean,
+                       float* running_var, int C, float* prm, void* stream);
+int pswin_stem_bn2_coefs(const float* sums, const float* prm, double count, int training, float* prm5, void* stream);
+int pswin_stem_conv1_wgrad(const float* out5, const float* xx, const void* w1p, const float* prm1, double count, int training,
+                           float* dw1, float* db1, void* stream);
 
 /* Column sums of a row-major [M, N] matrix in fp32: out[n] = sum_m x[m][n] (fixed summation order).  The bias
  * gradient of every Linear on the path (autograd of nn.Linear, HOT:50-52, 236, 323) and the reduction of split-K

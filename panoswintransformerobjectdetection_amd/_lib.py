@@ -45,9 +45,13 @@ _PROTOTYPES = {
     "pswin_stem_conv3_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
     "pswin_stem_conv3_bwd_stats": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
     "pswin_stem_conv3_bwd_data": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp],
-    "pswin_stem_conv3_wgrad": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
-    "pswin_stem_conv2_wgrad": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
+    "pswin_stem_conv3_wgrad": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
+    "pswin_stem_conv2_wgrad": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "pswin_stem_conv2_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
+    "pswin_stem_pack_weights": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "pswin_stem_bn_fold": [_vp, _vp, ctypes.c_double, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _i, _vp, _vp],
+    "pswin_stem_bn2_coefs": [_vp, _vp, ctypes.c_double, _i, _vp, _vp],
+    "pswin_stem_conv1_wgrad": [_vp, _vp, _vp, _vp, ctypes.c_double, _i, _vp, _vp, _vp],
     "pswin_bias_gelu_fwd": [_vp, _i, _vp, _vp, ctypes.c_longlong, _i, _vp],
     "pswin_bias_gelu_workspace": [ctypes.c_longlong, _i],
     "pswin_bias_gelu_tune": [_i, _i],

@@ -328,6 +328,26 @@ class BasicLayer(nn.Module, DoubleModeModule):
         return y, H, W, self.downsample(x, H, W, cd), (H + 1) // 2, (W + 1) // 2
 
 
+class _ApeAdd(torch.autograd.Function):
+    """x + Linear(feat)[None]  (the absolute position encoding, HOT:926-934: feat [S, 5] is input independent).
+    Backward without a framework two-pass reduction: the bias gradient (a sum over all S tokens) goes through
+    pswin_colsum.  torch's global reductions return stale results from the second replay of a captured hipGraph on this
+    stack (the semaphore memset node is not re-run: tools/dbg_graph3.py), which silently corrupted this one gradient."""
+
+    @staticmethod
+    def forward(ctx, x, feat, weight, bias):
+        ctx.save_for_backward(feat, weight)
+        return x + F.linear(feat, weight, bias)[None]
+
+    @staticmethod
+    def backward(ctx, g):
+        feat, weight = ctx.saved_tensors
+        gs = g.sum(0) if g.shape[0] > 1 else g[0]              # [S, C]: a per-element sum over the batch (one pass)
+        dw = gs.t() @ feat                                      # [C, 5]
+        db = ops.colsum(gs.contiguous())
+        return g, None, dw, db
+
+
 class _ChannelBias(torch.autograd.Function):
     """y + bias over the channel dim of a channels-last NCHW tensor; the bias gradient is a column sum over the
     [N*H*W, C] row view (pswin_colsum).  Keeps the convolution bias out of MIOpen's ConvolutionBackwardBias, whose
@@ -501,7 +521,7 @@ class SimplePanoSwinTransformer(nn.Module, DoubleModeModule):
         x, Wh, Ww = self.patch_embed(x_bchw.float(), cd)
         if self.pano_mode and self.ape:
             feat = ops.abs_pos_features(Wh, Ww, x.device)                               # HOT:926-934
-            x = x + F.linear(feat, self.abs_encoder.weight, self.abs_encoder.bias)[None]
+            x = _ApeAdd.apply(x, feat, self.abs_encoder.weight, self.abs_encoder.bias)
         outs = []
         dp_all = self._draw_drop_path(x) if self.training else None
         for i, layer in enumerate(self.layers):

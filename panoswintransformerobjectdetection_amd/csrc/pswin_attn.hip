@@ -1025,29 +1025,35 @@ __global__ __launch_bounds__(DTAB_THREADS) void dtab_partial_kernel(const float*
     }
 }
 
-// Stage 2 (after the fixed-order column sum over blocks): one thread per (table entry, head) adds its <= 49 pairs.
-// summed: [heads][2][49*49]
-__global__ void dtab_final_kernel(const float* __restrict__ summed, int heads, bool has_dist,
-                                  float* __restrict__ dalpha, float* __restrict__ dbeta) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;   // over 169 * heads
+// Stage 2 (after the fixed-order column sum over blocks): one WAVE per (table entry, head): lane l < 49 is the key
+// position (hj, wj) = (l / 7, l % 7) and loads the one pair (i, j) with hi - hj = dh, wi - wj = dw if it exists; a
+// butterfly reduction (fixed order) finishes the bin.  (One thread per bin walking its <= 49 pairs was a chain of
+// dependent loads: 17 us for 507 outputs.)   summed: [heads][2][49*49]
+__global__ __launch_bounds__(256) void dtab_final_kernel(const float* __restrict__ summed, int heads, bool has_dist,
+                                                         float* __restrict__ dalpha, float* __restrict__ dbeta) {
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);     // over 169 * heads, wave-uniform
+    const int lane = threadIdx.x & 63;
     if (t >= NBINS * heads) return;
     const int idx = t / heads, h = t - idx * heads;
     const int dh = idx / (2 * PSWIN_WS - 1) - (PSWIN_WS - 1), dw = idx % (2 * PSWIN_WS - 1) - (PSWIN_WS - 1);
     const float* p = summed + (size_t)h * 2 * TOK * TOK;
+    const int hj = lane / PSWIN_WS, wj = lane - hj * PSWIN_WS;
+    const int hi = hj + dh, wi = wj + dw;
     float sb = 0.f, sa = 0.f;
-    for (int hj = 0; hj < PSWIN_WS; ++hj) {        // pairs with hi - hj = dh and wi - wj = dw
-        const int hi = hj + dh;
-        if (hi < 0 || hi >= PSWIN_WS) continue;
-        for (int wj = 0; wj < PSWIN_WS; ++wj) {
-            const int wi = wj + dw;
-            if (wi < 0 || wi >= PSWIN_WS) continue;
-            const int e = (hj * PSWIN_WS + wj) * TOK + hi * PSWIN_WS + wi;   // j * 49 + i
-            sb += p[e];
-            if (has_dist) sa += p[TOK * TOK + e];
-        }
+    if (lane < TOK && hi >= 0 && hi < PSWIN_WS && wi >= 0 && wi < PSWIN_WS) {
+        const int e = lane * TOK + hi * PSWIN_WS + wi;     // j * 49 + i
+        sb = p[e];
+        if (has_dist) sa = p[TOK * TOK + e];
     }
-    dbeta[t] = sb;
-    if (dalpha) dalpha[t] = sa;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        sb += __shfl_xor(sb, m, 64);
+        sa += __shfl_xor(sa, m, 64);
+    }
+    if (lane == 0) {
+        dbeta[t] = sb;
+        if (dalpha) dalpha[t] = sa;
+    }
 }
 
 // Work items per bias window.  More chunks = more independent waves but the per-item setup (bias build, and the dS-sum
@@ -1177,7 +1183,7 @@ extern "C" int pswin_attn_table_grads(const float* dscore_sum, int n_tiles, int 
     hipLaunchKernelGGL(dtab_partial_kernel, dim3(blocks, heads), dim3(DTAB_THREADS), 0, (hipStream_t)stream, dscore_sum,
                        n_tiles, n_bias_windows, dist_t, dist_t ? n_dist : 1, heads, partial);
     launch_colsum(partial, blocks, ncol, summed, (hipStream_t)stream);
-    hipLaunchKernelGGL(dtab_final_kernel, dim3((NBINS * heads + 63) / 64), dim3(64), 0, (hipStream_t)stream, summed,
+    hipLaunchKernelGGL(dtab_final_kernel, dim3((NBINS * heads + 3) / 4), dim3(256), 0, (hipStream_t)stream, summed,
                        heads, dist_t != nullptr, dist_t ? dalpha : nullptr, dbeta);
     PSWIN_LAUNCH_RET();
 }

@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) void rowsum_direct_kernel(const void* __restri
     }
 }
 
-constexpr int ROWSUM_MAX_BLOCKS = 512;
+constexpr int ROWSUM_MAX_BLOCKS = 2048;
 constexpr int ROWSUM_DIRECT_MAX_ROWS = 1024;
 
 inline int rowsum_blocks(long long M, int N, int dtype) {

@@ -279,7 +279,7 @@ inline int pick_lanes(int C) {
 inline bool wide_row(int C) { return C > 1024; }
 constexpr int MAX_C = 2048;
 
-constexpr int BWD_MAX_BLOCKS = 512;
+constexpr int BWD_MAX_BLOCKS = 1536;    // 6 blocks of 4 waves per CU: with 512 only 2 waves per SIMD were resident (3.4 TB/s)
 
 inline int bwd_blocks(long long rows, int L) {
     const int rpb = THREADS / L;

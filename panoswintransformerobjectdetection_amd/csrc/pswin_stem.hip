@@ -480,6 +480,138 @@ __global__ __launch_bounds__(TWG) void stem_conv3_wgrad_kernel(const void* __res
             for (int e = 0; e < 4; ++e) out[((nt * 6 + mt) * 4 + e) * 64 + lane] = acc[nt][mt][e];
 }
 
+// ---------------------------------------------------------------------------------------------
+// Small parameter kernels (one launch each instead of dozens of framework element-wise launches per step)
+// ---------------------------------------------------------------------------------------------
+// weights f32 -> the packed bf16 operand layouts of the kernels above
+__global__ void stem_pack_weights_kernel(const float* __restrict__ w1, const float* __restrict__ w2,
+                                         const float* __restrict__ w3, unsigned short* __restrict__ w1p,
+                                         unsigned short* __restrict__ w2p, unsigned short* __restrict__ w2t,
+                                         unsigned short* __restrict__ w3p, unsigned short* __restrict__ w3t) {
+    constexpr int N1 = C1 * 48, N2 = 9 * C2 * C1, N3 = 16 * C3 * C2;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < N1 + 2 * N2 + 2 * N3; i += gridDim.x * blockDim.x) {
+        if (i < N1) {                                   // w1p[o][tap][ch] <- w1[o][ch][tap]
+            const int o = i / 48, r = i - 48 * o, tap = r >> 2, ch = r & 3;
+            w1p[i] = (tap < 9 && ch < 3) ? f32_to_bf16_bits(w1[(o * 3 + ch) * 9 + tap]) : (unsigned short)0;
+        } else if (i < N1 + N2) {                       // w2p[tap][o][in] <- w2[o][in][tap]
+            const int j = i - N1, tap = j / (C2 * C1), r = j - tap * C2 * C1, o = r / C1, in = r - o * C1;
+            w2p[j] = f32_to_bf16_bits(w2[(o * C1 + in) * 9 + tap]);
+        } else if (i < N1 + 2 * N2) {                   // w2t[tap][in][o]
+            const int j = i - N1 - N2, tap = j / (C2 * C1), r = j - tap * C2 * C1, in = r / C2, o = r - in * C2;
+            w2t[j] = f32_to_bf16_bits(w2[(o * C1 + in) * 9 + tap]);
+        } else if (i < N1 + 2 * N2 + N3) {              // w3p[tap][o][in] <- w3[o][in][tap]
+            const int j = i - N1 - 2 * N2, tap = j / (C3 * C2), r = j - tap * C3 * C2, o = r / C2, in = r - o * C2;
+            w3p[j] = f32_to_bf16_bits(w3[(o * C2 + in) * 16 + tap]);
+        } else {                                        // w3t[tap][in][o]
+            const int j = i - N1 - 2 * N2 - N3, tap = j / (C3 * C2), r = j - tap * C3 * C2, in = r / C3, o = r - in * C3;
+            w3t[j] = f32_to_bf16_bits(w3[(o * C2 + in) * 16 + tap]);
+        }
+    }
+}
+
+// BatchNorm folding: statistics of a bias-free convolution output -> prm[4][C] = scale, shift, rstd, -mean rstd;
+// training: batch statistics + nn.BatchNorm2d running-statistics update (the conv bias only shifts the tracked mean)
+__global__ void stem_bn_fold_kernel(const float* __restrict__ sum, const float* __restrict__ sumsq, double count,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    const float* __restrict__ conv_bias, float eps, float momentum, int training,
+                                    float* __restrict__ running_mean, float* __restrict__ running_var, int C,
+                                    float* __restrict__ prm) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float cb = conv_bias ? conv_bias[c] : 0.f;
+    float mean, var;
+    if (training) {
+        const double m = (double)sum[c] / count;
+        double v = (double)sumsq[c] / count - m * m;
+        v = v > 0.0 ? v : 0.0;
+        mean = (float)m;
+        var = (float)v;
+        if (running_mean) {
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (mean + cb);
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(v * (count / (count > 1.0 ? count - 1.0 : 1.0)));
+        }
+    } else {
+        mean = running_mean[c] - cb;
+        var = running_var[c];
+    }
+    const float rstd = 1.0f / sqrtf(var + eps);
+    const float sc = gamma[c] * rstd;
+    prm[c] = sc;
+    prm[C + c] = beta[c] - mean * sc;
+    prm[2 * C + c] = rstd;
+    prm[3 * C + c] = -mean * rstd;
+}
+
+// BN2 backward coefficients: sums[2][64] = (sum g, sum g yhat) -> prm5[5][64] = scale, shift, k1, P, Q for conv3_bwd_data
+__global__ void stem_bn2_coef_kernel(const float* __restrict__ sums, const float* __restrict__ prm, float count, int training,
+                                     float* __restrict__ prm5) {
+    const int c = threadIdx.x;
+    if (c >= C2) return;
+    const float sc = prm[c], sh = prm[C2 + c], a = prm[2 * C2 + c], b = prm[3 * C2 + c];
+    float P = 0.f, Q = 0.f;
+    if (training) {
+        const float m1 = sums[c] / count, m2 = sums[C2 + c] / count;
+        P = sc * a * m2;
+        Q = sc * (m1 + b * m2);
+    }
+    prm5[c] = sc;
+    prm5[C2 + c] = sh;
+    prm5[2 * C2 + c] = sc;
+    prm5[3 * C2 + c] = P;
+    prm5[4 * C2 + c] = Q;
+}
+
+// conv1 weight gradient from the correlations: dW1[o][ch][tap] = k1 (G - m1 X1 - m2 Y)[o][tap*4+ch],
+// X1 = XX[ones], Y = rstd (W1 XX - mean X1);  out5 = (sum g1, sum g1 yhat1, G[32][48]);  prm1 = scale, shift, rstd, -mean rstd
+__global__ void stem_conv1_wgrad_kernel(const float* __restrict__ out5, const float* __restrict__ xx,
+                                        const unsigned short* __restrict__ w1p, const float* __restrict__ prm1, float count,
+                                        int training, float* __restrict__ dw1, float* __restrict__ db1) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;       // over 32 * 27
+    if (i >= C1 * 27) return;
+    const int o = i / 27, r = i - 27 * o, ch = r / 9, tap = r - 9 * ch;
+    const int k = tap * 4 + ch;
+    const float sc = prm1[o], rstd = prm1[2 * C1 + o], nmr = prm1[3 * C1 + o];     // nmr = -mean rstd
+    const float G = out5[2 * C1 + o * 48 + k];
+    float v = G;
+    if (training) {
+        const float m1 = out5[o] / count, m2 = out5[C1 + o] / count;
+        const float X1 = xx[(4 * 4 + 3) * 48 + k];
+        float syx = 0.f;
+        for (int kk = 0; kk < 48; ++kk) syx = __builtin_fmaf(bf16_bits_to_f32(w1p[o * 48 + kk]), xx[kk * 48 + k], syx);
+        const float Y = rstd * syx + nmr * X1;
+        v = G - m1 * X1 - m2 * Y;
+    }
+    dw1[i] = sc * v;
+    if (r == 0 && db1) db1[o] = training ? 0.f : sc * out5[o];
+}
+
+// out[perm[c]] = sum_r part[r][c]: the column sum of the weight-gradient partials, written in parameter layout
+__global__ void colsum_perm_kernel(const float* __restrict__ part, int R, int N, const int* __restrict__ perm,
+                                   float* __restrict__ out) {
+    __shared__ float red[64][16];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < N) {
+        int r = rl;
+        for (; r + 64 < R; r += 128) {
+            s0 += part[(size_t)r * N + c];
+            s1 += part[(size_t)(r + 64) * N + c];
+        }
+        for (; r < R; r += 64) s0 += part[(size_t)r * N + c];
+    }
+    red[rl][cl] = s0 + s1;
+    __syncthreads();
+    if (rl < 16) red[rl][cl] = (red[rl][cl] + red[rl + 16][cl]) + (red[rl + 32][cl] + red[rl + 48][cl]);
+    __syncthreads();
+    if (rl == 0 && c < N) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += red[k][cl];
+        out[perm[c]] = s;
+    }
+}
+
 namespace t8 {
 #define STEM_TH 8
 #include "pswin_stem_tiles.inc"
@@ -579,7 +711,7 @@ int pswin_stem_conv3_bwd_data(const void* dtok, const void* y2, const float* prm
 }
 
 int pswin_stem_conv3_wgrad(const void* dtok, const void* y2, const float* scale2, const float* shift2, int B, int H, int W,
-                           float* dw3, float* workspace, void* stream) {
+                           const int32_t* perm, float* dw3, float* workspace, void* stream) {
     PSWIN_CHECK_ARG(dtok && y2 && scale2 && shift2 && dw3 && workspace && B > 0 && H > 0 && W > 0 && H % 4 == 0 && W % 4 == 0);
     const long long M = (long long)B * (H / 4) * (W / 4);
     PSWIN_CHECK_ARG(M < 0x7fffffffll - 64);
@@ -590,19 +722,27 @@ int pswin_stem_conv3_wgrad(const void* dtok, const void* y2, const float* scale2
     PSWIN_CHECK_ARG((long long)splits * 4 * WG3_OUT <= (long long)pswin_stem_workspace(B, H, W));
     hipLaunchKernelGGL(stem_conv3_wgrad_kernel, dim3(splits, 4), dim3(TWG), 0, (hipStream_t)stream, dtok, y2, scale2, shift2, H,
                        W, (int)M, per, workspace);
-    launch_colsum(workspace, splits, 4 * WG3_OUT, dw3, (hipStream_t)stream);
+    if (perm)
+        hipLaunchKernelGGL(colsum_perm_kernel, dim3((4 * WG3_OUT + 15) / 16), dim3(1024), 0, (hipStream_t)stream, workspace, splits,
+                           4 * WG3_OUT, perm, dw3);
+    else
+        launch_colsum(workspace, splits, 4 * WG3_OUT, dw3, (hipStream_t)stream);
     PSWIN_LAUNCH_RET();
 }
 
 int pswin_stem_conv2_wgrad(const void* x4, const void* w1p, const float* scale1, const float* shift1, const void* dy2, int B,
-                           int H, int W, float* dw2, float* workspace, void* stream) {
+                           int H, int W, const int32_t* perm, float* dw2, float* workspace, void* stream) {
     PSWIN_CHECK_ARG(x4 && w1p && scale1 && shift1 && dy2 && dw2 && workspace && B > 0 && H > 0 && W > 0);
     using namespace t8;
     const int nty = (H + TH - 1) / TH, ntx = (W + TW - 1) / TW, ntiles = B * nty * ntx;
     const int grid = grid_for(ntiles, 2);
     hipLaunchKernelGGL(stem_conv2_wgrad_kernel, dim3(grid), dim3(WG), 0, (hipStream_t)stream, reinterpret_cast<const u64*>(x4),
                        w1p, scale1, shift1, dy2, H, W, nty, ntx, ntiles, workspace);
-    launch_colsum(workspace, grid, WG2_OUT, dw2, (hipStream_t)stream);
+    if (perm)
+        hipLaunchKernelGGL(colsum_perm_kernel, dim3((WG2_OUT + 15) / 16), dim3(1024), 0, (hipStream_t)stream, workspace, grid, WG2_OUT,
+                           perm, dw2);
+    else
+        launch_colsum(workspace, grid, WG2_OUT, dw2, (hipStream_t)stream);
     PSWIN_LAUNCH_RET();
 }
 
@@ -615,6 +755,38 @@ int pswin_stem_conv2_bwd(const void* x4, const void* w1p, const float* prm, cons
     hipLaunchKernelGGL(stem_conv2_bwd_kernel, dim3(grid), dim3(WG), 0, (hipStream_t)stream, reinterpret_cast<const u64*>(x4),
                        w1p, prm, dy2, w2t, H, W, nty, ntx, ntiles, workspace);
     launch_colsum(workspace, grid * NW, PART5, out, (hipStream_t)stream);
+    PSWIN_LAUNCH_RET();
+}
+
+int pswin_stem_pack_weights(const float* w1, const float* w2, const float* w3, void* w1p, void* w2p, void* w2t, void* w3p,
+                            void* w3t, void* stream) {
+    PSWIN_CHECK_ARG(w1 && w2 && w3 && w1p && w2p && w2t && w3p && w3t);
+    hipLaunchKernelGGL(stem_pack_weights_kernel, dim3(256), dim3(256), 0, (hipStream_t)stream, w1, w2, w3,
+                       (unsigned short*)w1p, (unsigned short*)w2p, (unsigned short*)w2t, (unsigned short*)w3p, (unsigned short*)w3t);
+    PSWIN_LAUNCH_RET();
+}
+
+int pswin_stem_bn_fold(const float* sum, const float* sumsq, double count, const float* gamma, const float* beta,
+                       const float* conv_bias, float eps, float momentum, int training, float* running_mean,
+                       float* running_var, int C, float* prm, void* stream) {
+    PSWIN_CHECK_ARG(gamma && beta && prm && C > 0 && C <= 1024 && count > 0);
+    PSWIN_CHECK_ARG(training ? (sum && sumsq) : (running_mean && running_var));
+    hipLaunchKernelGGL(stem_bn_fold_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, sum, sumsq, count, gamma,
+                       beta, conv_bias, eps, momentum, training, running_mean, running_var, C, prm);
+    PSWIN_LAUNCH_RET();
+}
+
+int pswin_stem_bn2_coefs(const float* sums, const float* prm, double count, int training, float* prm5, void* stream) {
+    PSWIN_CHECK_ARG(sums && prm && prm5 && count > 0);
+    hipLaunchKernelGGL(stem_bn2_coef_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, sums, prm, (float)count, training, prm5);
+    PSWIN_LAUNCH_RET();
+}
+
+int pswin_stem_conv1_wgrad(const float* out5, const float* xx, const void* w1p, const float* prm1, double count, int training,
+                           float* dw1, float* db1, void* stream) {
+    PSWIN_CHECK_ARG(out5 && w1p && prm1 && dw1 && count > 0 && (!training || xx));
+    hipLaunchKernelGGL(stem_conv1_wgrad_kernel, dim3((C1 * 27 + 63) / 64), dim3(64), 0, (hipStream_t)stream, out5, xx,
+                       (const unsigned short*)w1p, prm1, (float)count, training, dw1, db1);
     PSWIN_LAUNCH_RET();
 }
 

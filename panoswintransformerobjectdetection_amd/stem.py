@@ -90,11 +90,28 @@ def decode_dw3(raw):
     return t.permute(4, 6, 5, 1, 3, 7, 0, 2).reshape(C3, C2, 4, 4)
 
 
-def conv3_wgrad(dtok, y2, scale2, shift2, ws):
+_PERMS = {}
+
+
+def _perm(name, decode, n, device):
+    """int32 table: accumulator element -> position in the parameter layout (the inverse of decode_*), cached per device"""
+    key = (name, str(device))
+    if key not in _PERMS:
+        src = decode(torch.arange(n, device=device, dtype=torch.float32)).reshape(-1).long()   # src[j]: accumulator index of output j
+        perm = torch.empty(n, device=device, dtype=torch.int32)
+        perm[src] = torch.arange(n, device=device, dtype=torch.int32)
+        _PERMS[key] = perm
+    return _PERMS[key]
+
+
+def conv3_wgrad(dtok, y2, scale2, shift2, ws, direct=True):
     B, H, W, _ = y2.shape
-    raw = torch.empty(4 * 8 * 12 * 256, device=y2.device, dtype=torch.float32)
-    _lib.call("pswin_stem_conv3_wgrad", y2, _ptr(dtok), _ptr(y2), _ptr(scale2), _ptr(shift2), B, H, W, _ptr(raw), _ptr(ws))
-    return decode_dw3(raw)
+    n = 4 * 8 * 12 * 256
+    raw = torch.empty(n, device=y2.device, dtype=torch.float32)
+    perm = _perm("dw3", decode_dw3, n, y2.device) if direct else None
+    _lib.call("pswin_stem_conv3_wgrad", y2, _ptr(dtok), _ptr(y2), _ptr(scale2), _ptr(shift2), B, H, W, _ptr(perm), _ptr(raw),
+              _ptr(ws))
+    return raw.view(C3, C2, 4, 4) if direct else decode_dw3(raw)
 
 
 def decode_dw2(raw):
@@ -103,42 +120,58 @@ def decode_dw2(raw):
     return t.permute(0, 1, 5, 4, 3, 6, 2).reshape(C2, C1, 3, 3)
 
 
-def conv2_wgrad(x4, w1p, scale1, shift1, dy2, ws):
+def conv2_wgrad(x4, w1p, scale1, shift1, dy2, ws, direct=True):
     B, H, W, _ = x4.shape
-    raw = torch.empty(2 * 36 * 256, device=x4.device, dtype=torch.float32)
-    _lib.call("pswin_stem_conv2_wgrad", x4, _ptr(x4), _ptr(w1p), _ptr(scale1), _ptr(shift1), _ptr(dy2), B, H, W, _ptr(raw),
-              _ptr(ws))
-    return decode_dw2(raw)
+    n = 2 * 36 * 256
+    raw = torch.empty(n, device=x4.device, dtype=torch.float32)
+    perm = _perm("dw2", decode_dw2, n, x4.device) if direct else None
+    _lib.call("pswin_stem_conv2_wgrad", x4, _ptr(x4), _ptr(w1p), _ptr(scale1), _ptr(shift1), _ptr(dy2), B, H, W, _ptr(perm),
+              _ptr(raw), _ptr(ws))
+    return raw.view(C2, C1, 3, 3) if direct else decode_dw2(raw)
 
 
-def conv2_bwd(x4, w1p, prm, dy2, w2t, ws):
+def conv2_bwd_raw(x4, w1p, prm, dy2, w2t, ws):
     B, H, W, _ = x4.shape
     out = torch.empty(2 * C1 + C1 * NSLOT, device=x4.device, dtype=torch.float32)
     _lib.call("pswin_stem_conv2_bwd", x4, _ptr(x4), _ptr(w1p), _ptr(prm), _ptr(dy2), _ptr(w2t), B, H, W, _ptr(out), _ptr(ws))
+    return out
+
+
+def conv2_bwd(x4, w1p, prm, dy2, w2t, ws):
+    out = conv2_bwd_raw(x4, w1p, prm, dy2, w2t, ws)
     return out[:C1], out[C1:2 * C1], out[2 * C1:].view(C1, NSLOT)
 
 
-def bn_fold(sum_, sumsq, count, bn, conv_bias, training):
-    """Batch statistics (training) or running statistics (eval) of a conv output whose bias was NOT applied ->
-    (scale, shift, mean, rstd), all f32 [C]; updates the BatchNorm buffers like nn.BatchNorm2d in training."""
-    if training:
-        mean64 = sum_.double() / count
-        var64 = (sumsq.double() / count - mean64 * mean64).clamp_min(0.0)
-        mean, var = mean64.float(), var64.float()
-        if bn.track_running_stats and bn.running_mean is not None:
-            with torch.no_grad():
-                bn.num_batches_tracked += 1
-                m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-                full_mean = mean if conv_bias is None else mean + conv_bias.detach().float()
-                bn.running_mean.mul_(1 - m).add_(full_mean, alpha=m)
-                bn.running_var.mul_(1 - m).add_(var * (count / max(count - 1, 1)), alpha=m)
-    else:
-        mean = bn.running_mean.float() if conv_bias is None else bn.running_mean.float() - conv_bias.detach().float()
-        var = bn.running_var.float()
-    rstd = torch.rsqrt(var + bn.eps)
-    scale = bn.weight.detach().float() * rstd
-    shift = bn.bias.detach().float() - mean * scale
-    return scale.contiguous(), shift.contiguous(), mean.contiguous(), rstd.contiguous()
+def pack_weights(w1, w2, w3):
+    """the five packed bf16 operands from the fp32 parameters: one launch"""
+    dev = w1.device
+    bf = torch.bfloat16
+    w1p = torch.empty(C1, 12, 4, device=dev, dtype=bf)
+    w2p, w2t = torch.empty(9, C2, C1, device=dev, dtype=bf), torch.empty(9, C1, C2, device=dev, dtype=bf)
+    w3p, w3t = torch.empty(16, C3, C2, device=dev, dtype=bf), torch.empty(16, C2, C3, device=dev, dtype=bf)
+    w1c, w2c, w3c = w1.detach().float().contiguous(), w2.detach().float().contiguous(), w3.detach().float().contiguous()
+    _lib.call("pswin_stem_pack_weights", w1c, _ptr(w1c), _ptr(w2c), _ptr(w3c), _ptr(w1p), _ptr(w2p), _ptr(w2t), _ptr(w3p),
+              _ptr(w3t))
+    return w1p, w2p, w2t, w3p, w3t
+
+
+def bn_fold_prm(sums, count, bn, conv_bias, training):
+    """-> prm f32 [4][C] = scale, shift, rstd, -mean rstd (one launch; updates bn's running statistics in training)"""
+    C = bn.num_features
+    prm = torch.empty(4, C, device=bn.weight.device, dtype=torch.float32)
+    momentum = bn.momentum
+    if training and bn.track_running_stats:
+        with torch.no_grad():
+            bn.num_batches_tracked += 1
+        if momentum is None:
+            momentum = 1.0 / float(bn.num_batches_tracked)
+    s = None if sums is None else sums[:C]
+    q = None if sums is None else sums[C:2 * C]
+    cb = None if conv_bias is None else conv_bias.detach()
+    _lib.call("pswin_stem_bn_fold", prm, _ptr(s), _ptr(q), float(count), _ptr(bn.weight.detach()), _ptr(bn.bias.detach()),
+              _ptr(cb), float(bn.eps), float(momentum or 0.0), int(training), _ptr(bn.running_mean), _ptr(bn.running_var), C,
+              _ptr(prm))
+    return prm
 
 
 class _Stem(torch.autograd.Function):
@@ -151,61 +184,46 @@ class _Stem(torch.autograd.Function):
         n = B * H * W
         ws = workspace(x)
         x4 = pack_input(x)
-        w1p = pack_w1(w1)
+        w1p, w2p, w2t, w3p, w3t = pack_weights(w1, w2, w3)
         need_grad = any(ctx.needs_input_grad[1:11])
-        if training:
-            sums = conv1_stats(x4, w1p, ws, want_xx=need_grad)
-            s1, q1, xx = sums[:C1], sums[C1:2 * C1], sums[2 * C1:].view(NSLOT, NSLOT)
-        else:
-            s1 = q1 = xx = None
-        sc1, sh1, mean1, rstd1 = bn_fold(s1, q1, n, bn1, b1, training)
-        y2, sums2 = conv2_fwd(x4, w1p, sc1, sh1, pack_taps(w2, False), ws, want_stats=training)
-        s2, q2 = (sums2[:C2], sums2[C2:]) if training else (None, None)
-        sc2, sh2, mean2, rstd2 = bn_fold(s2, q2, n, bn2, b2, training)
-        tok = conv3_fwd(y2, sc2, sh2, pack_taps(w3, False), b3.detach().float().contiguous())
+        sums1 = conv1_stats(x4, w1p, ws, want_xx=need_grad) if training else None
+        prm1 = bn_fold_prm(sums1, n, bn1, b1, training)
+        y2, sums2 = conv2_fwd(x4, w1p, prm1[0], prm1[1], w2p, ws, want_stats=training)
+        prm2 = bn_fold_prm(sums2, n, bn2, b2, training)
+        tok = conv3_fwd(y2, prm2[0], prm2[1], w3p, b3.detach().float().contiguous())
         ctx.training = training
-        ctx.save_for_backward(x4, y2, w1p, w2, w3, sc1, sh1, mean1, rstd1, sc2, sh2, mean2, rstd2,
-                              xx if xx is not None else sc1)
+        ctx.save_for_backward(x4, y2, w1p, w2t, w3t, prm1, prm2, sums1 if sums1 is not None else prm1)
         return tok
 
     @staticmethod
     def backward(ctx, dtok):
-        x4, y2, w1p, w2, w3, sc1, sh1, mean1, rstd1, sc2, sh2, mean2, rstd2, xx = ctx.saved_tensors
+        x4, y2, w1p, w2t, w3t, prm1, prm2, sums1 = ctx.saved_tensors
         training = ctx.training
         B, H, W, _ = x4.shape
         n = float(B * H * W)
-        ws = torch.empty(_lib.load().pswin_stem_workspace(B, H, W), device=x4.device, dtype=torch.float32)
+        dev = x4.device
+        ws = torch.empty(_lib.load().pswin_stem_workspace(B, H, W), device=dev, dtype=torch.float32)
         dtok = dtok.to(torch.bfloat16).contiguous()
-        w3t, w2t = pack_taps(w3, True), pack_taps(w2, True)
-        # BN2 backward sums, then dy2
-        b2c = -mean2 * rstd2
-        s = conv3_bwd_stats(dtok, y2, torch.stack([sc2, sh2, rstd2, b2c]).contiguous(), w3t, ws)
-        dbe2, dg2 = s[:C2].clone(), s[C2:].clone()
-        if training:
-            m1, m2 = dbe2 / n, dg2 / n
-            P, Q = sc2 * rstd2 * m2, sc2 * (m1 + b2c * m2)
-        else:
-            P = Q = torch.zeros_like(sc2)
-        dy2 = conv3_bwd_data(dtok, y2, torch.stack([sc2, sh2, sc2, P, Q]).contiguous(), w3t)
-        dw3 = conv3_wgrad(dtok, y2, sc2, sh2, ws).clone()
-        cs_ws = torch.empty(_lib.load().pswin_colsum_workspace(dtok.shape[0], C3, _lib.BF16), device=x4.device,
-                            dtype=torch.float32)
-        db3 = torch.empty(C3, device=x4.device, dtype=torch.float32)
+        # BN2 backward sums (= dbeta2, dgamma2), then dy2
+        s2 = conv3_bwd_stats(dtok, y2, prm2, w3t, ws)
+        prm5 = torch.empty(5, C2, device=dev, dtype=torch.float32)
+        _lib.call("pswin_stem_bn2_coefs", s2, _ptr(s2), _ptr(prm2), n, int(training), _ptr(prm5))
+        dy2 = conv3_bwd_data(dtok, y2, prm5, w3t)
+        dw3 = conv3_wgrad(dtok, y2, prm2[0], prm2[1], ws)
+        cs_ws = torch.empty(_lib.load().pswin_colsum_workspace(dtok.shape[0], C3, _lib.BF16), device=dev, dtype=torch.float32)
+        db3 = torch.empty(C3, device=dev, dtype=torch.float32)
         _lib.call("pswin_colsum", dtok, _ptr(dtok), _lib.BF16, dtok.shape[0], C3, _ptr(db3), _ptr(cs_ws))
-        dw2 = conv2_wgrad(x4, w1p, sc1, sh1, dy2, ws).clone()
-        b1c = -mean1 * rstd1
-        sg, sgy, G = conv2_bwd(x4, w1p, torch.stack([sc1, sh1, rstd1, b1c]).contiguous(), dy2, w2t, ws)
-        dbe1, dg1 = sg.clone(), sgy.clone()
-        if training:
-            # dW1 = gamma rstd (G - mean(g1) X1 - mean(g1 yhat1) Y), X1 = sum xp, Y = sum yhat1 (x) xp = rstd (W1 XX - mean X1)
-            X1 = xx[ONES]
-            Y = rstd1[:, None] * (w1p.float().view(C1, NSLOT) @ xx - mean1[:, None] * X1[None, :])
-            dw1p = sc1[:, None] * (G - (sg / n)[:, None] * X1[None, :] - (sgy / n)[:, None] * Y)
-            db1, db2 = torch.zeros_like(sg), torch.zeros_like(dbe2)      # a bias in front of a BatchNorm has no gradient
-        else:
-            dw1p = sc1[:, None] * G
-            db1, db2 = sc1 * sg, sc2 * dbe2
-        dw1 = dw1p.view(C1, 12, 4)[:, :9, :3].permute(0, 2, 1).reshape(C1, 3, 3, 3).contiguous()
+        dw2 = conv2_wgrad(x4, w1p, prm1[0], prm1[1], dy2, ws)
+        out5 = conv2_bwd_raw(x4, w1p, prm1, dy2, w2t, ws)
+        # dW1 = gamma rstd (G - mean(g1) X1 - mean(g1 yhat1) Y), X1 = sum xp, Y = sum yhat1 (x) xp = rstd (W1 XX - mean X1)
+        dw1 = torch.empty(C1, 3, 3, 3, device=dev, dtype=torch.float32)
+        db1 = torch.empty(C1, device=dev, dtype=torch.float32)
+        xx = sums1[2 * C1:] if training else None
+        _lib.call("pswin_stem_conv1_wgrad", out5, _ptr(out5), _ptr(xx), _ptr(w1p), _ptr(prm1), n, int(training), _ptr(dw1),
+                  _ptr(db1))
+        dbe2, dg2 = s2[:C2], s2[C2:]
+        dbe1, dg1 = out5[:C1], out5[C1:2 * C1]
+        db2 = torch.zeros_like(dbe2) if training else prm2[0] * dbe2     # a bias in front of a BatchNorm has no gradient
         return None, dw1, db1, dg1, dbe1, dw2, db2, dg2, dbe2, dw3, db3, None, None, None
 
 

@@ -117,12 +117,18 @@ def test_stem_backward_pieces(B, H, W):
     dw3_ref = torch.nn.grad.conv2d_weight(a2r, w3.shape, dt_img, stride=4)
     dw3 = stem.conv3_wgrad(dtok, y2k, sc2, sh2, ws)
     assert _relerr(dw3, dw3_ref) < 2e-3
+    assert torch.equal(dw3, stem.conv3_wgrad(dtok, y2k, sc2, sh2, ws, direct=False))      # in-kernel layout == host decode
     # conv2 weight gradient (a1 recomputed in-kernel) and data gradient pieces, on a bf16 dy2
     dy2b = dy2k
     dy2f = dy2b.float().permute(0, 3, 1, 2)
     dw2_ref = torch.nn.grad.conv2d_weight(a1, w2.shape, dy2f, padding=1)
     dw2 = stem.conv2_wgrad(x4, w1p, sc1, sh1, dy2b, ws)
     assert _relerr(dw2, dw2_ref) < 3e-3
+    assert torch.equal(dw2, stem.conv2_wgrad(x4, w1p, sc1, sh1, dy2b, ws, direct=False))
+    packed = stem.pack_weights(w1, w2, w3)
+    for got, want in zip(packed, (w1p, stem.pack_taps(w2, False), stem.pack_taps(w2, True), stem.pack_taps(w3, False),
+                                  stem.pack_taps(w3, True))):
+        assert torch.equal(got, want)
     mean1 = (torch.randn(32, generator=g) * 0.2).to(dev)
     rstd1 = (torch.rand(32, generator=g) + 0.5).to(dev)
     prm1 = torch.stack([sc1, sh1, rstd1, -mean1 * rstd1]).contiguous()

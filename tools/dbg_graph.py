@@ -10,8 +10,11 @@ m = SimplePanoSwinTransformer(**TCFG, compute_dtype=torch.bfloat16); m.init_weig
 red = GradReducer(m, pack=pack)
 opt = torch.optim.AdamW(m.parameters(), lr=1e-4, weight_decay=0.05, fused=True, capturable=True)
 x = torch.randn(8, 3, 512, 1024, device="cuda")
+with torch.no_grad():
+    LW = [torch.randn_like(o).flatten() / o.numel() for o in m(x)]
+OUTS = []
 def fb():
-    red.zero_grad(); loss = sum(o.float().mean() for o in m(x)); loss.backward()
+    red.zero_grad(); outs = m(x); OUTS[:] = outs; loss = sum(o.float().flatten() @ w for o, w in zip(outs, LW)); loss.backward()
     if pack: red.pack_grads()
     return loss
 g = GraphedCallable(fb, warmup=2)
@@ -23,7 +26,8 @@ def stats():
     bad = [k for k, p in m.named_parameters() if not torch.isfinite(p).all()]
     worst = sorted(((p.grad.abs().max().item(), k) for k, p in m.named_parameters() if p.grad is not None), reverse=True)[:4]
     pw = sorted(((p.abs().max().item(), k) for k, p in m.named_parameters()), reverse=True)[:2]
+    print("      outs finite", [bool(torch.isfinite(o).all()) for o in OUTS], "out absmax", [float(o.abs().max()) for o in OUTS])
     return f"flat max {red.flat.abs().max().item():.4g} worst grads {worst} largest params {pw}"
-for i in range(4):
+for i in range(8):
     l = g(); print("replay", i, "loss", l.item(), stats(), flush=True)
     go(); print("   after opt", stats(), flush=True)
