@@ -49,7 +49,7 @@ def pack_input(x):
 def conv1_stats(x4, w1p, ws, want_xx=True):
     B, H, W, _ = x4.shape
     sums = torch.empty(2 * C1 + NSLOT * NSLOT, device=x4.device, dtype=torch.float32)
-    _lib.call("pswin_stem_conv1_stats", x4, _ptr(x4), _ptr(w1p), B, H, W, int(want_xx), _ptr(sums), _ptr(ws))
+    _lib.call("pswin_stem_conv1_stats", x4, _ptr(x4), _ptr(w1p), B, H, W, int(want_xx), _ptr(sums), _ptr(ws), algo_bytes=B * H * W * 8)
     return sums
 
 
@@ -58,28 +58,28 @@ def conv2_fwd(x4, w1p, scale1, shift1, w2p, ws, want_stats=True):
     y2 = torch.empty(B, H, W, C2, device=x4.device, dtype=torch.bfloat16)
     sums2 = torch.empty(2 * C2, device=x4.device, dtype=torch.float32) if want_stats else None
     _lib.call("pswin_stem_conv2_fwd", x4, _ptr(x4), _ptr(w1p), _ptr(scale1), _ptr(shift1), _ptr(w2p), B, H, W, _ptr(y2),
-              _ptr(sums2), _ptr(ws))
+              _ptr(sums2), _ptr(ws), algo_bytes=B * H * W * 136)
     return y2, sums2
 
 
 def conv3_fwd(y2, scale2, shift2, w3p, bias3):
     B, H, W, _ = y2.shape
     tok = torch.empty(B * (H // 4) * (W // 4), C3, device=y2.device, dtype=torch.bfloat16)
-    _lib.call("pswin_stem_conv3_fwd", y2, _ptr(y2), _ptr(scale2), _ptr(shift2), _ptr(w3p), _ptr(bias3), B, H, W, _ptr(tok))
+    _lib.call("pswin_stem_conv3_fwd", y2, _ptr(y2), _ptr(scale2), _ptr(shift2), _ptr(w3p), _ptr(bias3), B, H, W, _ptr(tok), algo_bytes=B * H * W * 128 + tok.numel() * 2)
     return tok
 
 
 def conv3_bwd_stats(dtok, y2, prm, w3t, ws):
     B, H, W, _ = y2.shape
     sums = torch.empty(2 * C2, device=y2.device, dtype=torch.float32)
-    _lib.call("pswin_stem_conv3_bwd_stats", y2, _ptr(dtok), _ptr(y2), _ptr(prm), _ptr(w3t), B, H, W, _ptr(sums), _ptr(ws))
+    _lib.call("pswin_stem_conv3_bwd_stats", y2, _ptr(dtok), _ptr(y2), _ptr(prm), _ptr(w3t), B, H, W, _ptr(sums), _ptr(ws), algo_bytes=B * H * W * 128 + dtok.numel() * 2)
     return sums
 
 
 def conv3_bwd_data(dtok, y2, prm, w3t):
     B, H, W, _ = y2.shape
     dy2 = torch.empty_like(y2)
-    _lib.call("pswin_stem_conv3_bwd_data", y2, _ptr(dtok), _ptr(y2), _ptr(prm), _ptr(w3t), B, H, W, _ptr(dy2))
+    _lib.call("pswin_stem_conv3_bwd_data", y2, _ptr(dtok), _ptr(y2), _ptr(prm), _ptr(w3t), B, H, W, _ptr(dy2), algo_bytes=B * H * W * 256 + dtok.numel() * 2)
     return dy2
 
 
@@ -110,7 +110,7 @@ def conv3_wgrad(dtok, y2, scale2, shift2, ws, direct=True):
     raw = torch.empty(n, device=y2.device, dtype=torch.float32)
     perm = _perm("dw3", decode_dw3, n, y2.device) if direct else None
     _lib.call("pswin_stem_conv3_wgrad", y2, _ptr(dtok), _ptr(y2), _ptr(scale2), _ptr(shift2), B, H, W, _ptr(perm), _ptr(raw),
-              _ptr(ws))
+              _ptr(ws), algo_bytes=B * H * W * 128 + dtok.numel() * 2)
     return raw.view(C3, C2, 4, 4) if direct else decode_dw3(raw)
 
 
@@ -126,14 +126,14 @@ def conv2_wgrad(x4, w1p, scale1, shift1, dy2, ws, direct=True):
     raw = torch.empty(n, device=x4.device, dtype=torch.float32)
     perm = _perm("dw2", decode_dw2, n, x4.device) if direct else None
     _lib.call("pswin_stem_conv2_wgrad", x4, _ptr(x4), _ptr(w1p), _ptr(scale1), _ptr(shift1), _ptr(dy2), B, H, W, _ptr(perm),
-              _ptr(raw), _ptr(ws))
+              _ptr(raw), _ptr(ws), algo_bytes=B * H * W * 136)
     return raw.view(C2, C1, 3, 3) if direct else decode_dw2(raw)
 
 
 def conv2_bwd_raw(x4, w1p, prm, dy2, w2t, ws):
     B, H, W, _ = x4.shape
     out = torch.empty(2 * C1 + C1 * NSLOT, device=x4.device, dtype=torch.float32)
-    _lib.call("pswin_stem_conv2_bwd", x4, _ptr(x4), _ptr(w1p), _ptr(prm), _ptr(dy2), _ptr(w2t), B, H, W, _ptr(out), _ptr(ws))
+    _lib.call("pswin_stem_conv2_bwd", x4, _ptr(x4), _ptr(w1p), _ptr(prm), _ptr(dy2), _ptr(w2t), B, H, W, _ptr(out), _ptr(ws), algo_bytes=B * H * W * 136)
     return out
 
 

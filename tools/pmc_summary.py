@@ -10,7 +10,7 @@ the same kernels on the same shapes.
 import csv, json, sys
 from collections import defaultdict
 
-KERNELS = {"attn_fwd_kernel": "pswin_attn_fwd", "attn_bwd_kernel": "pswin_attn_bwd", "ln_fwd_kernel": "pswin_ln_gather_fwd",
+KERNELS = {"attn_fwd_kernel": "pswin_attn_fwd", "attn_bwd_kernel": "pswin_attn_bwd", "attn_bwd_pair_kernel": "pswin_attn_bwd", "ln_fwd_kernel": "pswin_ln_gather_fwd",
            "ln_bwd_kernel": "pswin_ln_gather_bwd", "window_gather_kernel": "pswin_window_gather",
            "window_scatter_add_kernel": "pswin_window_scatter_add"}
 
