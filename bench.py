@@ -107,7 +107,10 @@ def main():
     model = model.to(dev).train()
     reducer = GradReducer(model, bucket_mb=args.bucket_mb, pack=not args.eager)
     reducer.broadcast_parameters(model)
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, betas=(0.9, 0.999), weight_decay=0.05, fused=True,
+    # one parameter group (as the reference's AdamW config): the optimizer runs over ONE flat parameter / gradient /
+    # state buffer (dp.GradReducer.flatten_parameters), i.e. a single fused element-wise launch per step
+    opt_params = [reducer.flatten_parameters(model, cd if cd != torch.float32 else None)] if not args.eager else list(model.parameters())
+    opt = torch.optim.AdamW(opt_params, lr=1e-4, betas=(0.9, 0.999), weight_decay=0.05, fused=True,
                             capturable=not args.eager)
 
     torch.manual_seed(1234 + rank)               # every rank its own shard of synthetic panoramas

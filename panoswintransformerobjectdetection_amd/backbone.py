@@ -493,6 +493,10 @@ class SimplePanoSwinTransformer(nn.Module, DoubleModeModule):
     def _refresh_lowp(self, cd):
         """bf16 copies of every Linear weight / bias on the path, refreshed by one multi-tensor cast per forward
         (instead of ~100 small cast kernels); plain attributes, never part of the state dict."""
+        fp = self.__dict__.get("_flat_pair")
+        if fp is not None and fp[1].dtype == cd:
+            fp[1].copy_(fp[0])                      # every master weight -> its low-precision view, one kernel
+            return
         lins = [m for m in self.modules() if isinstance(m, nn.Linear) and m is not getattr(self, "abs_encoder", None)]
         src, dst = [], []
         for m in lins:
@@ -506,6 +510,23 @@ class SimplePanoSwinTransformer(nn.Module, DoubleModeModule):
                 src.append(m.bias)
                 dst.append(lp[1])
         torch._foreach_copy_(dst, src)
+
+    def _attach_flat_lowp(self, flat_master, flat_lowp):
+        """Called by dp.GradReducer.flatten_parameters: all parameters are views of `flat_master`; make the low-precision
+        shadows of the Linear layers views of `flat_lowp` at the same offsets, so that one cast refreshes them all."""
+        base = flat_master.data_ptr()
+        for m in self.modules():
+            if isinstance(m, nn.Linear) and m is not getattr(self, "abs_encoder", None):
+                views = []
+                for p in (m.weight, m.bias):
+                    if p is None:
+                        views.append(None)
+                        continue
+                    off = (p.data_ptr() - base) // 4
+                    assert 0 <= off and off + p.numel() <= flat_master.numel(), "parameter is not a view of the flat buffer"
+                    views.append(flat_lowp[off:off + p.numel()].view_as(p))
+                m.__dict__["_lowp"] = tuple(views)
+        self.__dict__["_flat_pair"] = (flat_master, flat_lowp)
 
     def forward(self, x_bchw, pano_ratio_v=None):
         if pano_ratio_v is not None:

@@ -86,3 +86,33 @@ def test_two_rank_gradient_average(pack):
             assert torch.allclose(torch.from_numpy(res[r][1][k]), want, rtol=1e-5, atol=1e-7), (k, r)
     assert torch.equal(torch.from_numpy(res[0][1]["unused"]), torch.zeros(5))
     assert not torch.allclose(torch.from_numpy(res[0][3]), torch.from_numpy(res[1][3]))   # BN stats stay per rank
+
+
+def test_flatten_parameters_single_tensor_adamw_matches_per_parameter_adamw():
+    """dp.GradReducer.flatten_parameters: parameters become views of one flat buffer; AdamW on that single tensor
+    (with the flat gradient buffer as its .grad) takes the same steps as AdamW over the individual parameters."""
+    import copy
+    import torch
+    from panoswintransformerobjectdetection_amd.dp import GradReducer
+    torch.manual_seed(0)
+    ref = torch.nn.Sequential(torch.nn.Linear(7, 5), torch.nn.LayerNorm(5), torch.nn.Linear(5, 3))
+    mod = copy.deepcopy(ref)
+    red = GradReducer(mod, pack=True)
+    flat = red.flatten_parameters()
+    for p, q in zip(mod.parameters(), ref.parameters()):
+        assert torch.equal(p.data, q.data)
+        assert p.data.data_ptr() >= flat.data_ptr() and p.data.data_ptr() < flat.data_ptr() + flat.numel() * 4
+    o_ref = torch.optim.AdamW(ref.parameters(), lr=1e-2, weight_decay=0.05)
+    o_mod = torch.optim.AdamW([flat], lr=1e-2, weight_decay=0.05)
+    x = torch.randn(11, 7)
+    for _ in range(3):
+        o_ref.zero_grad()
+        ref(x).square().mean().backward()
+        o_ref.step()
+        red.zero_grad()
+        mod(x).square().mean().backward()
+        red.pack_grads()
+        red.finish()
+        o_mod.step()
+    for p, q in zip(mod.parameters(), ref.parameters()):
+        assert torch.allclose(p.data, q.data, rtol=1e-6, atol=1e-7)
