@@ -138,6 +138,17 @@ int pswin_ln_gather_bwd(const void* dy, int dy_dtype, const int32_t* inv, const 
                         float* dres_sum, void* dx, float* dgamma, float* dbeta, float* workspace, int B, int S, int n_out,
                         int C, void* stream);
 
+/* Output norms: y = LayerNorm(x) written channel-major, i.e. norm{i}(x).view(B, H, W, C).permute(0, 3, 1, 2).contiguous()
+ * of HOT:975-977 in one pass (x: f32 [B, S, C]; y: f32 [B, C, S]; mean, rstd: f32 [B, S]), and its backward from the
+ * NCHW gradient dy f32 [B, C, S] (dres as in pswin_ln_gather_bwd; workspace: pswin_ln_workspace(B * S, C) elements).
+ * pswin_ln_nchw_supported(S, C) != 0 when the token count per image fits the kernels' tiling (S % (256 / lanes(C)) == 0). */
+int pswin_ln_nchw_supported(int S, int C);
+int pswin_ln_nchw_fwd(const float* x, const float* gamma, const float* beta, float eps, float* y, float* mean, float* rstd,
+                      int B, int S, int C, void* stream);
+int pswin_ln_nchw_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                      const float* dres, float* dx, float* dgamma, float* dbeta, float* workspace, int B, int S, int C,
+                      void* stream);
+
 /* Workspace elements for the LayerNorm backward kernels over `rows` walked rows of width C. */
 int pswin_ln_workspace(long long rows, int C);
 

@@ -319,10 +319,10 @@ class BasicLayer(nn.Module, DoubleModeModule):
                 x = blk(x, H, W, cd, *extra)
         y = x
         if out_norm is not None:                    # output norm first: the downsample branch's gradient then joins
-            if self.downsample is not None:         # the stream inside the norm's backward kernel
-                y, x = ops.layer_norm_gather(x, out_norm.weight, out_norm.bias, out_norm.eps, passthrough=True)
+            if self.downsample is not None:         # the stream inside the norm's backward kernel; NCHW written directly
+                y, x = ops.layer_norm_nchw(x, out_norm.weight, out_norm.bias, out_norm.eps, H, W, passthrough=True)
             else:
-                y = ops.layer_norm_gather(x, out_norm.weight, out_norm.bias, out_norm.eps)
+                y = ops.layer_norm_nchw(x, out_norm.weight, out_norm.bias, out_norm.eps, H, W)
         if self.downsample is None:
             return y, H, W, x, H, W
         return y, H, W, self.downsample(x, H, W, cd), (H + 1) // 2, (W + 1) // 2
@@ -549,7 +549,7 @@ class SimplePanoSwinTransformer(nn.Module, DoubleModeModule):
             nl = getattr(self, f"norm{i}") if i in self.out_indices else None
             y, H, W, x, Wh, Ww = layer(x, Wh, Ww, cd, nl, None if dp_all is None else dp_all[i])
             if nl is not None:
-                outs.append(y.view(-1, H, W, self.num_features[i]).permute(0, 3, 1, 2).contiguous())
+                outs.append(y)                                                          # already [B, C, H, W], HOT:975-977
         return tuple(outs)
 
     def _draw_drop_path(self, x):

@@ -235,6 +235,161 @@ __global__ __launch_bounds__(THREADS) void ln_bwd_kernel(const void* __restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Output norms (HOT:975-977: norm{i}(x_out) -> view(B, H, W, C) -> permute(0, 3, 1, 2).contiguous()):
+// LayerNorm written directly in NCHW.  A block normalises RPB = THREADS / L consecutive tokens, parks the result in an
+// LDS tile and writes it out channel-major, RPB * 4 bytes contiguous per channel, instead of a token-major store plus a
+// separate strided transpose pass over the (largest) output tensor; the backward kernel reads the NCHW gradient the
+// same way.  fp32 in, fp32 out; S % RPB == 0 (the host falls back to LN + copy otherwise).
+// ---------------------------------------------------------------------------------------------
+template <int L, int NCH>
+__global__ __launch_bounds__(THREADS) void ln_nchw_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, float eps,
+                                                              float* __restrict__ y, float* __restrict__ mean,
+                                                              float* __restrict__ rstd, int S, int C) {
+    constexpr int RPB = THREADS / L;
+    extern __shared__ float tile[];                 // [C][RPB + 1]
+    const int lane = threadIdx.x % L, rsub = threadIdx.x / L;
+    const long long row = (long long)blockIdx.x * RPB + rsub;       // grid covers B * S exactly
+    const int nchunks = C / 4;
+    f32x4 v[NCH];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int ch = lane + k * L;
+        v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ch < nchunks) {
+            v[k] = *reinterpret_cast<const f32x4*>(x + (size_t)row * C + 4 * ch);
+            s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+        }
+    }
+    const float mu = row_sum<L>(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int ch = lane + k * L;
+        if (ch < nchunks) {
+            const f32x4 d = v[k] - mu;
+            q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        }
+    }
+    const float rs_ = rsqrtf(row_sum<L>(q) / (float)C + eps);
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int ch = lane + k * L;
+        if (ch < nchunks) {
+            const f32x4 g4 = *reinterpret_cast<const f32x4*>(gamma + 4 * ch);
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(beta + 4 * ch);
+            const f32x4 o = (v[k] - mu) * rs_ * g4 + b4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tile[(4 * ch + e) * (RPB + 1) + rsub] = o[e];
+        }
+    }
+    if (lane == 0) {
+        mean[row] = mu;
+        rstd[row] = rs_;
+    }
+    __syncthreads();
+    const long long row0 = (long long)blockIdx.x * RPB;
+    const int b = (int)(row0 / S);
+    const int t0 = (int)(row0 - (long long)b * S);
+    float* yb = y + (size_t)b * C * S + t0;
+    constexpr int Q = RPB / 4;                       // 16-byte groups per channel
+    for (int i = threadIdx.x; i < C * Q; i += THREADS) {
+        const int c = i / Q, r4 = i - c * Q;
+        const float* tp = tile + c * (RPB + 1) + 4 * r4;
+        *reinterpret_cast<f32x4*>(yb + (size_t)c * S + 4 * r4) = f32x4{tp[0], tp[1], tp[2], tp[3]};
+    }
+}
+
+template <int L, int NCH>
+__global__ __launch_bounds__(THREADS) void ln_nchw_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                              const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                              const float* __restrict__ gamma, const float* __restrict__ dres,
+                                                              float* __restrict__ dx, float* __restrict__ part,
+                                                              long long rows, int S, int C) {
+    constexpr int RPB = THREADS / L;
+    constexpr int Q = RPB / 4;
+    extern __shared__ float tile[];                 // [RPB][C + 4] then the partial-sum staging
+    __shared__ float red[2][THREADS * 4];
+    const int lane = threadIdx.x % L, rsub = threadIdx.x / L;
+    const int nchunks = C / 4, LD = C + 4;
+    f32x4 dg[NCH], db[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) dg[k] = db[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (long long row0 = (long long)blockIdx.x * RPB; row0 < rows; row0 += (long long)gridDim.x * RPB) {
+        const int b = (int)(row0 / S);
+        const int t0 = (int)(row0 - (long long)b * S);
+        const float* dyb = dy + (size_t)b * C * S + t0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < C * Q; i += THREADS) {
+            const int c = i / Q, r4 = i - c * Q;
+            const f32x4 t = *reinterpret_cast<const f32x4*>(dyb + (size_t)c * S + 4 * r4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tile[(4 * r4 + e) * LD + c] = t[e];
+        }
+        __syncthreads();
+        const long long row = row0 + rsub;
+        const float mu = mean[row], rs_ = rstd[row];
+        f32x4 xh[NCH], g[NCH];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int ch = lane + k * L;
+            xh[k] = g[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ch < nchunks) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)row * C + 4 * ch);
+                const f32x4 dyv = *reinterpret_cast<const f32x4*>(tile + rsub * LD + 4 * ch);
+                const f32x4 g4 = *reinterpret_cast<const f32x4*>(gamma + 4 * ch);
+                xh[k] = (xv - mu) * rs_;
+                g[k] = dyv * g4;
+                dg[k] = dg[k] + dyv * xh[k];
+                db[k] = db[k] + dyv;
+                s1 += (g[k][0] + g[k][1]) + (g[k][2] + g[k][3]);
+                s2 += (g[k][0] * xh[k][0] + g[k][1] * xh[k][1]) + (g[k][2] * xh[k][2] + g[k][3] * xh[k][3]);
+            }
+        }
+        s1 = row_sum<L>(s1) / (float)C;
+        s2 = row_sum<L>(s2) / (float)C;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int ch = lane + k * L;
+            if (ch < nchunks) {
+                f32x4 v = (g[k] - s1 - xh[k] * s2) * rs_;
+                if (dres) v = v + *reinterpret_cast<const f32x4*>(dres + (size_t)row * C + 4 * ch);
+                *reinterpret_cast<f32x4*>(dx + (size_t)row * C + 4 * ch) = v;
+            }
+        }
+    }
+    float* outp = part + (size_t)blockIdx.x * 2 * C;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int ch = lane + k * L;
+        __syncthreads();
+        if (ch < nchunks) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                red[0][(rsub * L + lane) * 4 + e] = dg[k][e];
+                red[1][(rsub * L + lane) * 4 + e] = db[k][e];
+            }
+        }
+        __syncthreads();
+        if (rsub == 0 && ch < nchunks) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a = 0.f, c = 0.f;
+#pragma unroll 4
+                for (int q = 0; q < RPB; ++q) {
+                    a += red[0][(q * L + lane) * 4 + e];
+                    c += red[1][(q * L + lane) * 4 + e];
+                }
+                outp[4 * ch + e] = a;
+                outp[C + 4 * ch + e] = c;
+            }
+        }
+    }
+}
+
 // out_k[c] = sum_r part[r][k * C + c] for the nseg (2 or 3) segments of rows of nseg * C floats; 16 columns x 64 row lanes
 __global__ void colsum_seg_kernel(const float* __restrict__ part, int R, int C, int nseg, float* __restrict__ out_a,
                                   float* __restrict__ out_b, float* __restrict__ out_c) {
@@ -432,5 +587,56 @@ extern "C" int pswin_ln_patch_merge_bwd(const void* dy, int dy_dtype, const void
     });
     if (rc) return rc;
     launch_colsum_seg(workspace, blocks, C4, 2, dgamma, dbeta, nullptr, (hipStream_t)stream);
+    PSWIN_LAUNCH_RET();
+}
+
+extern "C" int pswin_ln_nchw_supported(int S, int C) {
+    if (S <= 0 || C < 8 || C % 8 || C > 1024) return 0;
+    const int L = pick_lanes(C);
+    const int rpb = THREADS / L;
+    return (rpb >= 4 && S % rpb == 0) ? 1 : 0;
+}
+
+extern "C" int pswin_ln_nchw_fwd(const float* x, const float* gamma, const float* beta, float eps, float* y, float* mean,
+                                 float* rstd, int B, int S, int C, void* stream) {
+    PSWIN_CHECK_ARG(x && gamma && beta && y && mean && rstd && B > 0 && pswin_ln_nchw_supported(S, C));
+    PSWIN_CHECK_ARG(aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta));
+    const int L = pick_lanes(C), rpb = THREADS / L;
+    const long long rows = (long long)B * S;
+    const unsigned grid = (unsigned)(rows / rpb);
+    const size_t lds = (size_t)C * (rpb + 1) * sizeof(float);
+#define PSWIN_LN_NCHW_F(LL)                                                                                               \
+    case LL:                                                                                                              \
+        hipLaunchKernelGGL((ln_nchw_fwd_kernel<LL, 4>), dim3(grid), dim3(THREADS), lds, (hipStream_t)stream, x, gamma, beta, \
+                           eps, y, mean, rstd, S, C);                                                                     \
+        break;
+    switch (L) {
+        PSWIN_LN_NCHW_F(2) PSWIN_LN_NCHW_F(4) PSWIN_LN_NCHW_F(8) PSWIN_LN_NCHW_F(16) PSWIN_LN_NCHW_F(32) PSWIN_LN_NCHW_F(64)
+        default: return PSWIN_ERR_ARG;
+    }
+#undef PSWIN_LN_NCHW_F
+    PSWIN_LAUNCH_RET();
+}
+
+extern "C" int pswin_ln_nchw_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                                 const float* dres, float* dx, float* dgamma, float* dbeta, float* workspace, int B, int S,
+                                 int C, void* stream) {
+    PSWIN_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && workspace && B > 0 && pswin_ln_nchw_supported(S, C));
+    PSWIN_CHECK_ARG(aligned16(dy) && aligned16(x) && aligned16(dx) && aligned16(gamma) && aligned16(dres));
+    const int L = pick_lanes(C), rpb = THREADS / L;
+    const long long rows = (long long)B * S;
+    const int blocks = bwd_blocks(rows, L);
+    const size_t lds = (size_t)rpb * (C + 4) * sizeof(float);
+#define PSWIN_LN_NCHW_B(LL)                                                                                              \
+    case LL:                                                                                                             \
+        hipLaunchKernelGGL((ln_nchw_bwd_kernel<LL, 4>), dim3(blocks), dim3(THREADS), lds, (hipStream_t)stream, dy, x, mean, \
+                           rstd, gamma, dres, dx, workspace, rows, S, C);                                                \
+        break;
+    switch (L) {
+        PSWIN_LN_NCHW_B(2) PSWIN_LN_NCHW_B(4) PSWIN_LN_NCHW_B(8) PSWIN_LN_NCHW_B(16) PSWIN_LN_NCHW_B(32) PSWIN_LN_NCHW_B(64)
+        default: return PSWIN_ERR_ARG;
+    }
+#undef PSWIN_LN_NCHW_B
+    launch_colsum_seg(workspace, blocks, C, 2, dgamma, dbeta, nullptr, (hipStream_t)stream);
     PSWIN_LAUNCH_RET();
 }

@@ -262,6 +262,51 @@ def layer_norm_gather(x, gamma, beta, eps, wmap=None, inv=None, out_dtype=None, 
     return _LayerNormGather.apply(x, gamma, beta, eps, wmap, inv, out_dtype or x.dtype, passthrough, res_bias, res_scale)
 
 
+class _LayerNormNCHW(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, H, W, passthrough):
+        B, S, C = x.shape
+        x = x.contiguous()
+        y = torch.empty(B, C, H, W, dtype=torch.float32, device=x.device)
+        mean = torch.empty(B, S, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        call("pswin_ln_nchw_fwd", x, ptr(x), ptr(gamma), ptr(beta), float(eps), ptr(y), ptr(mean), ptr(rstd), B, S, C,
+             algo_bytes=2 * x.numel() * 4)
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        if passthrough:
+            return y, x.view_as(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy, dres=None):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        B, S, C = x.shape
+        if dy is None:
+            return dres, torch.zeros_like(gamma), torch.zeros_like(gamma), None, None, None, None
+        dy = dy.float().contiguous()
+        if dres is not None:
+            dres = dres.float().contiguous()
+        dx = torch.empty_like(x)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        ws = torch.empty(_lib.load().pswin_ln_workspace(B * S, C), dtype=torch.float32, device=x.device)
+        call("pswin_ln_nchw_bwd", x, ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(dres), ptr(dx), ptr(dgamma),
+             ptr(dbeta), ptr(ws), B, S, C, algo_bytes=(3 if dres is None else 4) * x.numel() * 4)
+        return dx, dgamma, dbeta, None, None, None, None
+
+
+def layer_norm_nchw(x, gamma, beta, eps, H, W, passthrough=False):
+    """LayerNorm over the channels of x [B, H*W, C] (fp32) returned as a contiguous NCHW map [B, C, H, W]: the output
+    norms of the backbone (HOT:975-977) without the separate transpose pass, forward and backward.  Falls back to
+    layer_norm_gather + permute when the shape does not fit the kernel's tiling."""
+    B, S, C = x.shape
+    if x.dtype != torch.float32 or not _lib.load().pswin_ln_nchw_supported(S, C):
+        out = layer_norm_gather(x, gamma, beta, eps, passthrough=passthrough)
+        y, x2 = out if passthrough else (out, None)
+        y = y.float().view(B, H, W, C).permute(0, 3, 1, 2).contiguous()
+        return (y, x2) if passthrough else y
+    return _LayerNormNCHW.apply(x, gamma, beta, eps, H, W, passthrough)
+
+
 class _LayerNormPatchMerge(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps, H, W, out_dtype):

@@ -403,3 +403,30 @@ def test_residual_bias_pair(ops, use_scale):
     out = ops.window_scatter_add(win, xd, wmap, inv, scale, biasd)
     (out * gout).sum().backward()
     assert torch.allclose(biasd.grad, res[0][4], rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.parametrize("H,W,C", [(8, 16, 96), (16, 32, 192), (4, 8, 768), (16, 32, 96)])
+@pytest.mark.parametrize("passthrough", [False, True])
+def test_layer_norm_nchw(ops, H, W, C, passthrough):
+    """LayerNorm written straight into NCHW (the output norms) against F.layer_norm + permute, forward and backward,
+    with and without the residual passthrough."""
+    B = 2
+    x = det_uniform((B, H * W, C), "lnn:x", 2.0) + 0.2
+    gamma, beta = det_uniform((C,), "lnn:g", 0.5, 1.0), det_uniform((C,), "lnn:b", 0.5)
+    gy = det_uniform((B, C, H, W), "lnn:gy")
+    gx = det_uniform((B, H * W, C), "lnn:gx")
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (C,), gr, br, 1e-5).view(B, H, W, C).permute(0, 3, 1, 2)
+    loss = (ref * gy).sum() + ((xr * gx).sum() if passthrough else 0.0)
+    loss.backward()
+    xd, gd, bd = [t.to(DEV).requires_grad_(True) for t in (x, gamma, beta)]
+    assert ops._lib.load().pswin_ln_nchw_supported(H * W, C)
+    out = ops.layer_norm_nchw(xd, gd, bd, 1e-5, H, W, passthrough=passthrough)
+    y, x2 = out if passthrough else (out, None)
+    assert y.shape == (B, C, H, W) and y.is_contiguous()
+    l2 = (y * gy.to(DEV)).sum() + ((x2 * gx.to(DEV)).sum() if passthrough else 0.0)
+    l2.backward()
+    assert torch.allclose(y.cpu(), ref, rtol=1e-5, atol=2e-6)
+    assert torch.allclose(xd.grad.cpu(), xr.grad, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(gd.grad.cpu(), gr.grad, rtol=1e-4, atol=1e-4 * gr.grad.abs().max().item())
+    assert torch.allclose(bd.grad.cpu(), br.grad, rtol=1e-4, atol=1e-4 * br.grad.abs().max().item())
