@@ -3,8 +3,11 @@
 usage: python tools/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>
 
 Corrections (MI355X_MICROARCH.md, HBM section): counters are in KiB; on gfx950 FETCH_SIZE reports exactly half of
-the bytes of a wide (16 B/lane) coalesced streaming read, which is how these kernels read -> fetch x 2.  WRITE_SIZE
-is exact for 16 B/lane streaming stores.  The first launches (warm-up, lazily built tables) are included; they are
+the bytes of a wide (16 B/lane) coalesced streaming read (128-byte requests tallied at 64 B) -> fetch x 2 for the
+kernels that read whole rows; "other access widths are uncalibrated", so the attention kernels' pattern (64-byte
+head segments of rows 576+ B apart) was calibrated on known byte counts with tools/pmc_calib.py: a 64-byte segment
+per row reads back EXACT (17.7 MB counted for 17.6 MB), the wide clone of the same tensor half (79.4 for 158.7 MB)
+-> factor 1 for pswin_attn_fwd / pswin_attn_bwd.  WRITE_SIZE is exact for 16 B/lane streaming stores.  The first launches (warm-up, lazily built tables) are included; they are
 the same kernels on the same shapes.
 """
 import csv, json, sys
@@ -27,12 +30,15 @@ def collect(path, counter):
     return acc
 
 
+FETCH_FACTOR = {"pswin_attn_fwd": 1.0, "pswin_attn_bwd": 1.0}      # calibrated (see above); default 2.0 (wide row reads)
 fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
 out = {}
 for name in sorted(set(fetch) | set(write)):
     f, nf = fetch.get(name, [0, 1])
     w, nw = write.get(name, [0, 1])
-    out[name] = {"launches": nf, "fetch_bytes_per_launch_raw": f / max(nf, 1), "fetch_bytes_per_launch_corrected": 2 * f / max(nf, 1),
-                 "write_bytes_per_launch": w / max(nw, 1), "hbm_bytes_per_launch": 2 * f / max(nf, 1) + w / max(nw, 1)}
+    k = FETCH_FACTOR.get(name, 2.0)
+    out[name] = {"launches": nf, "fetch_bytes_per_launch_raw": f / max(nf, 1), "fetch_correction": k,
+                 "fetch_bytes_per_launch_corrected": k * f / max(nf, 1),
+                 "write_bytes_per_launch": w / max(nw, 1), "hbm_bytes_per_launch": k * f / max(nf, 1) + w / max(nw, 1)}
 json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on bench.py", "kernels": out}, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))
