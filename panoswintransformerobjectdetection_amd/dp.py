@@ -86,16 +86,37 @@ class GradReducer:
         else:
             self.flat.zero_()
 
-    def pack_grads(self):
-        """pack mode: gather the freshly produced gradients into the flat buffer and re-point ``param.grad`` at it."""
-        have = [(v, p.grad) for v, p in zip(self._views, self._order) if p.grad is not None]
-        for v, p in zip(self._views, self._order):
+    def pack_grads(self, params=None):
+        """pack mode: gather the freshly produced gradients into the flat buffer and re-point ``param.grad`` at it.
+        params: restrict to these parameters (a step whose backward pass runs in pieces packs each piece's share)."""
+        pairs = list(zip(self._views, self._order))
+        if params is not None:
+            ids = {id(p) for p in params}
+            pairs = [(v, p) for v, p in pairs if id(p) in ids]
+        have = [(v, p.grad) for v, p in pairs if p.grad is not None]
+        for v, p in pairs:
             if p.grad is None:
                 v.zero_()                                         # parameter unused this step: contributes zeros
         if have:
             torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
-        for v, p in zip(self._views, self._order):
+        for v, p in pairs:
             p.grad = v
+
+    def buckets_within(self, params):
+        """Indices of the buckets that hold gradients of `params` only (they can be reduced as soon as those are packed)."""
+        ids = {id(p) for p in params}
+        ok, at = [], 0
+        for b, (_, _, n) in enumerate(self.buckets):
+            if all(id(p) in ids for p in self._order[at:at + n]):
+                ok.append(b)
+            at += n
+        return ok
+
+    def launch(self, bucket_ids):
+        """Start the all-reduce of these buckets now (asynchronously); finish() handles the rest and waits for all."""
+        if self.world > 1:
+            for b in bucket_ids:
+                self._launch(b)
 
     def _launch(self, b):
         if self._launched[b]:
@@ -160,3 +181,38 @@ class GradReducer:
             return
         for p in module.parameters():
             dist.broadcast(p.data, src=src, group=self.group)
+
+
+# -- backward in two pieces (all-reduce overlapped with the second piece) ------------------------------------------
+class BoundaryTap:
+    """Remembers the input activation of `module` of the latest forward pass: the cut between the 'late' layers (whose
+    gradients a backward pass finishes first) and the 'early' ones."""
+
+    def __init__(self, module):
+        self.x = None
+        self._hook = module.register_forward_pre_hook(lambda m, a: setattr(self, "x", a[0]))
+
+    def remove(self):
+        self._hook.remove()
+
+
+def split_parameters(model, late_prefixes):
+    late = [p for n, p in model.named_parameters() if n.startswith(tuple(late_prefixes))]
+    early = [p for n, p in model.named_parameters() if not n.startswith(tuple(late_prefixes))]
+    return late, early
+
+
+def backward_late(loss_late, xb, late_params):
+    """Backward of the part of the loss that depends on the layers after the cut: sets ``.grad`` of `late_params`,
+    returns d loss_late / d xb.  Together with backward_early this equals ``(loss_early + loss_late).backward()``."""
+    grads = torch.autograd.grad(loss_late, [xb] + list(late_params), allow_unused=True)
+    for p, g in zip(late_params, grads[1:]):
+        p.grad = g
+    return grads[0]
+
+
+def backward_early(loss_early, xb, g_xb, early_params):
+    grads = torch.autograd.grad([loss_early, xb], list(early_params),
+                                grad_outputs=[torch.ones_like(loss_early), g_xb], allow_unused=True)
+    for p, g in zip(early_params, grads):
+        p.grad = g

@@ -31,3 +31,37 @@ class GraphedCallable:
     def __call__(self):
         self.graph.replay()
         return self.out
+
+
+class GraphedSequence:
+    """Consecutive pieces of ONE step (e.g. forward + late-layer backward | early-layer backward) captured into separate
+    hipGraphs that share a memory pool, so that tensors produced by an earlier piece (activations, the autograd graph's
+    saved tensors) stay valid for the later ones.  Between two replays the host can launch work that must not be
+    captured -- the RCCL all-reduce of the gradients the first piece has already finished.  `calls[i]()` replays piece
+    i and returns what its function returned at capture time (static tensors)."""
+
+    def __init__(self, fns, warmup=2, stream=None):
+        self.stream = stream or torch.cuda.Stream()
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            for _ in range(warmup):
+                for fn in fns:
+                    out = fn()
+            del out
+        torch.cuda.current_stream().wait_stream(self.stream)
+        torch.cuda.synchronize()
+        self.graphs, self.outs = [], []
+        pool = None
+        for fn in fns:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=self.stream, pool=pool):
+                self.outs.append(fn())
+            pool = pool or g.pool()
+            self.graphs.append(g)
+        self.calls = [self._make(i) for i in range(len(fns))]
+
+    def _make(self, i):
+        def call():
+            self.graphs[i].replay()
+            return self.outs[i]
+        return call
