@@ -51,3 +51,38 @@ def test_missing_library_fails_loudly(tmp_path, monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.PswinError):
         _lib.load()
+
+
+def test_checkpoint_loader_semantics(tmp_path):
+    """init_weights(pretrained=path): prefix stripping, state_dict / model wrappers, Swin key remap, bicubic resize of a
+    position-bias table trained with another window size (reference: mmcv_custom/checkpoint.py:286-356)."""
+    import torch
+    import torch.nn.functional as F
+    from panoswintransformerobjectdetection_amd import SimplePanoSwinTransformer
+    from panoswintransformerobjectdetection_amd.checkpoint import load_checkpoint
+    cfg = dict(embed_dim=96, depths=[2, 2, 2, 2], num_heads=[3, 6, 12, 24], window_size=7, ape=True, pano_mode=True)
+    torch.manual_seed(0)
+    src = SimplePanoSwinTransformer(**cfg)
+    sd = {k: torch.randn_like(v) if v.is_floating_point() else v.clone() for k, v in src.state_dict().items()}
+    wrapped = {"state_dict": {"module.backbone." + k: v for k, v in sd.items()}}
+    wrapped["state_dict"]["module.neck.lateral.weight"] = torch.zeros(3)                     # detector parts are skipped
+    # a vanilla-Swin style table for window 12 ((2*12-1)^2 = 529 rows) under the reference Swin key
+    key = "layers.0.blocks.0.attn.sphere_position_beta_table_Te"
+    big = torch.randn(529, 3)
+    del wrapped["state_dict"]["module.backbone." + key]
+    wrapped["state_dict"]["module.backbone.layers.0.blocks.0.attn.relative_position_bias_table"] = big
+    path = tmp_path / "ckpt.pth"
+    torch.save(wrapped, path)
+    dst = SimplePanoSwinTransformer(**cfg)
+    missing, unexpected = load_checkpoint(dst, str(path))
+    assert not missing and not unexpected
+    got = dst.state_dict()
+    for k, v in sd.items():
+        if k != key:
+            assert torch.equal(got[k], v), k
+    want = F.interpolate(big.permute(1, 0).reshape(1, 3, 23, 23), size=(13, 13), mode="bicubic").reshape(3, 169).permute(1, 0)
+    assert torch.allclose(got[key], want)
+    # init_weights goes through the same loader
+    dst2 = SimplePanoSwinTransformer(**cfg)
+    dst2.init_weights(str(path))
+    assert torch.equal(dst2.state_dict()["patch_embed.proj.0.weight"], sd["patch_embed.proj.0.weight"])
