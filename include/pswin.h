@@ -270,6 +270,15 @@ int pswin_stem_bn2_coefs(const float* sums, const float* prm, double count, int 
 int pswin_stem_conv1_wgrad(const float* out5, const float* xx, const void* w1p, const float* prm1, double count, int training,
                            float* dw1, float* db1, void* stream);
 
+/* Streaming GEMM for the Linear layers of the high-resolution stages (qkv / proj / fc1 / fc2 of stage 0, HOT:287, 309,
+ * 50-58; proj of stage 1):  y[M, N] = x[M, K] . W^T (+ bias), bf16 in / out, f32 accumulation, the whole weight resident
+ * in LDS.  transpose_w == 0: w is [N, K] (nn.Linear layout, forward pass); transpose_w != 0: w is [K, N], i.e. the
+ * data gradient dx[M, K'] = dy[M, N'] . W with w = the same nn.Linear weight [N', K'] passed as K = N', N = K'.
+ * bias: f32 [N] or NULL.  pswin_gemm_skinny_supported(K, N) != 0 for the (K, N) pairs the kernel is instantiated for. */
+int pswin_gemm_skinny_supported(int K, int N);
+int pswin_gemm_skinny(const void* x, const void* w, const float* bias, void* y, long long M, int K, int N, int transpose_w,
+                      void* stream);
+
 /* Column sums of a row-major [M, N] matrix in fp32: out[n] = sum_m x[m][n] (fixed summation order).  The bias
  * gradient of every Linear on the path (autograd of nn.Linear, HOT:50-52, 236, 323) and the reduction of split-K
  * weight-gradient partials.  N % 8 == 0; workspace: f32, pswin_colsum_workspace(M, N, dtype) elements. */

@@ -55,6 +55,8 @@ _PROTOTYPES = {
     "pswin_stem_bn_fold": [_vp, _vp, ctypes.c_double, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _i, _vp, _vp],
     "pswin_stem_bn2_coefs": [_vp, _vp, ctypes.c_double, _i, _vp, _vp],
     "pswin_stem_conv1_wgrad": [_vp, _vp, _vp, _vp, ctypes.c_double, _i, _vp, _vp, _vp],
+    "pswin_gemm_skinny_supported": [_i, _i],
+    "pswin_gemm_skinny": [_vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _i, _vp],
     "pswin_bias_gelu_fwd": [_vp, _i, _vp, _vp, ctypes.c_longlong, _i, _vp],
     "pswin_bias_gelu_workspace": [ctypes.c_longlong, _i],
     "pswin_bias_gelu_tune": [_i, _i],

@@ -1,0 +1,176 @@
+// Streaming GEMM for the Linear layers of the high-resolution stages (gfx950):  Y[M, N] = X[M, K] . W^T (+ bias)
+//
+// PanoSwin-T's stage-0 projections (qkv / proj / fc1 / fc2, HOT:287, 309, 50-58) have K, N <= 384 against M = 262k-276k
+// rows: they are HBM-bound streaming operators (212 MB moved for 15 GFLOP in qkv), yet the library's general GEMM
+// kernels reach only 1.9-3 TB/s on them (qkv forward: 113 us in the step, 45 us of traffic at 4.7 TB/s).  Here the
+// whole weight matrix (<= 80 KB) is staged ONCE per workgroup into LDS as MFMA A operands (rows = output column,
+// contraction contiguous; 16 bytes of row padding make the 16-byte reads of 8 rows conflict-free), every wave streams
+// 32 (16) rows of X straight from HBM in MFMA B-operand layout (a row's 16-byte chunk IS the operand fragment: no
+// staging, no transposes; rows beyond M return zeros through the buffer range check), and writes its bf16 output
+// rows with 16-byte stores (accumulator quads of two column tiles exchanged across lane groups).  The same kernel
+// computes the data gradient dX = dY . W by staging the transposed weight (transpose done while writing the LDS image).
+// bf16 operands, f32 accumulation on v_mfma_f32_16x16x32_bf16: the arithmetic of the library path.
+#include "pswin_common.hpp"
+
+using namespace pswin;
+
+namespace {
+
+constexpr int THREADS = 256;
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+
+__device__ inline f32x4 mfma32(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+__device__ inline void swap16_u32(unsigned& a, unsigned& b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(a, b, false, false);
+    a = r[0];
+    b = r[1];
+}
+__device__ inline unsigned pack_bf16(float lo, float hi) {
+    return (unsigned)f32_to_bf16_bits(lo) | ((unsigned)f32_to_bf16_bits(hi) << 16);
+}
+// lane (c, g) holds quads q0 = col[4g..4g+3], q1 = col[16+4g..16+4g+3] of a 32-column group of one row -> after the
+// exchange 8 consecutive columns starting at 8 (g >> 1) + 16 (g & 1)
+__device__ inline u32x4 pack_row8(f32x4 q0, f32x4 q1) {
+    unsigned a0 = pack_bf16(q0[0], q0[1]), a1 = pack_bf16(q0[2], q0[3]);
+    unsigned b0 = pack_bf16(q1[0], q1[1]), b1 = pack_bf16(q1[2], q1[3]);
+    swap16_u32(a0, b0);
+    swap16_u32(a1, b1);
+    return u32x4{a0, a1, b0, b1};
+}
+
+// KS = K / 32 contraction steps, NT = N / 16 output-column tiles (even), RT = 16-row tiles per wave iteration
+template <int KS, int NT, int RT>
+__global__ __launch_bounds__(THREADS, 2) void skinny_gemm_kernel(const void* __restrict__ x, const void* __restrict__ w,
+                                                                 const float* __restrict__ bias, void* __restrict__ y,
+                                                                 int M, int transpose_w) {
+    constexpr int K = 32 * KS, N = 16 * NT, LD = 2 * K + 16;           // LDS row stride in bytes
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* wl = smem;                                                     // [N][LD]
+    float* bl = reinterpret_cast<float*>(smem + N * LD);                 // [N]
+    if (!transpose_w) {                                                  // w: [N][K] (nn.Linear layout)
+        for (int i = threadIdx.x; i < N * (K / 8); i += THREADS) {
+            const int row = i / (K / 8), ch = i - row * (K / 8);
+            *reinterpret_cast<u32x4*>(wl + row * LD + ch * 16) = reinterpret_cast<const u32x4*>(w)[i];
+        }
+    } else {                                                             // w: [K][N] -> image[n][k]
+        const unsigned short* ws = reinterpret_cast<const unsigned short*>(w);
+        for (int i = threadIdx.x; i < K * (N / 8); i += THREADS) {
+            const int k = i / (N / 8), n0 = (i - k * (N / 8)) * 8;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(ws + (size_t)k * N + n0);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                *reinterpret_cast<unsigned short*>(wl + (n0 + 2 * d) * LD + 2 * k) = (unsigned short)(v[d] & 0xffffu);
+                *reinterpret_cast<unsigned short*>(wl + (n0 + 2 * d + 1) * LD + 2 * k) = (unsigned short)(v[d] >> 16);
+            }
+        }
+    }
+    for (int i = threadIdx.x; i < N; i += THREADS) bl[i] = bias ? bias[i] : 0.f;
+    __syncthreads();
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int c = lane & 15, g = lane >> 4;
+    const rsrc_t xs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(x), 0, (int)((size_t)M * K * 2), 0x00020000);
+    const rsrc_t ys = __builtin_amdgcn_make_buffer_rsrc(y, 0, (int)((size_t)M * N * 2), 0x00020000);
+    constexpr int ROWS = 16 * RT;
+    const int ntiles = (M + ROWS - 1) / ROWS;
+    const int d0 = 8 * (g >> 1) + 16 * (g & 1);
+    auto load_b = [&](int tile, bf16x8 (&b)[RT][KS]) {
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const unsigned row = (unsigned)tile * ROWS + 16 * rt + c;
+            const unsigned off = row < (unsigned)M ? row * (unsigned)(K * 2) + 16u * g : 0xFFFFFF00u;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const unsigned o = off == 0xFFFFFF00u ? off : off + 64u * s;
+                b[rt][s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xs, o, 0, 0));
+            }
+        }
+    };
+    for (int tile = blockIdx.x * (THREADS / 64) + wave; tile < ntiles; tile += gridDim.x * (THREADS / 64)) {
+        bf16x8 b[RT][KS];
+        load_b(tile, b);
+        f32x4 acc[RT][NT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[rt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // weight fragments in batches of 6 column tiles, double buffered in registers: the next batch's LDS reads are in
+        // flight under the current batch's MFMAs; the scheduling barriers keep the compiler from hoisting all KS * NT
+        // reads to the top (which spilled ~290 registers)
+        constexpr int BT = 6, NB = KS * (NT / BT);
+        static_assert(NT % BT == 0, "column tiles come in batches of 6");
+        bf16x8 a[2][BT];
+        auto read_batch = [&](int bi, bf16x8 (&dst)[BT]) {
+            const int s_ = bi / (NT / BT), nt0 = (bi - s_ * (NT / BT)) * BT;
+#pragma unroll
+            for (int j = 0; j < BT; ++j)
+                dst[j] = *reinterpret_cast<const bf16x8*>(wl + (16 * (nt0 + j) + c) * LD + (32 * s_ + 8 * g) * 2);
+        };
+        read_batch(0, a[0]);
+#pragma unroll
+        for (int bi = 0; bi < NB; ++bi) {
+            if (bi + 1 < NB) read_batch(bi + 1, a[(bi + 1) & 1]);
+            const int s_ = bi / (NT / BT), nt0 = (bi - s_ * (NT / BT)) * BT;
+#pragma unroll
+            for (int j = 0; j < BT; ++j)
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) acc[rt][nt0 + j] = mfma32(a[bi & 1][j], b[rt][s_], acc[rt][nt0 + j]);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // acc[rt][nt][e] = Y[row 16 rt + c][column 16 nt + 4 g + e]
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) {
+            const unsigned row = (unsigned)tile * ROWS + 16 * rt + c;
+            const unsigned base = row < (unsigned)M ? row * (unsigned)(N * 2) + 2u * d0 : 0xFFFFFF00u;
+#pragma unroll
+            for (int np = 0; np < NT / 2; ++np) {
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(bl + 32 * np + 4 * g);
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(bl + 32 * np + 16 + 4 * g);
+                const u32x4 v = pack_row8(acc[rt][2 * np] + b0, acc[rt][2 * np + 1] + b1);
+                __builtin_amdgcn_raw_buffer_store_b128(v, ys, base == 0xFFFFFF00u ? base : base + 64u * np, 0, 0);
+            }
+        }
+    }
+}
+
+template <int KS, int NT, int RT>
+int launch(const void* x, const void* w, const float* bias, void* y, int M, int transpose_w, hipStream_t st) {
+    constexpr int K = 32 * KS, N = 16 * NT;
+    constexpr size_t lds = (size_t)N * (2 * K + 16) + N * sizeof(float);
+    static bool configured = false;
+    if (!configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_gemm_kernel<KS, NT, RT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        configured = true;
+    }
+    const int ntiles = (M + 16 * RT - 1) / (16 * RT);
+    int grid = (ntiles + 3) / 4;
+    if (grid > 512) grid = 512;                       // 2 workgroups per CU, persistent over the row tiles
+    hipLaunchKernelGGL((skinny_gemm_kernel<KS, NT, RT>), dim3(grid), dim3(THREADS), lds, st, x, w, bias, y, M, transpose_w);
+    PSWIN_LAUNCH_RET();
+}
+
+}  // namespace
+
+extern "C" {
+
+int pswin_gemm_skinny_supported(int K, int N) {
+    return (K == 96 && (N == 96 || N == 288 || N == 384)) || (K == 288 && N == 96) || (K == 384 && N == 96) ||
+           (K == 192 && N == 192);
+}
+
+int pswin_gemm_skinny(const void* x, const void* w, const float* bias, void* y, long long M, int K, int N, int transpose_w,
+                      void* stream) {
+    PSWIN_CHECK_ARG(x && w && y && M > 0 && pswin_gemm_skinny_supported(K, N));
+    PSWIN_CHECK_ARG(M * (long long)(K > N ? K : N) * 2 < 0xFFFFFF00ll && aligned16(x) && aligned16(w) && aligned16(y));
+    hipStream_t st = (hipStream_t)stream;
+    const int m = (int)M;
+    if (K == 96 && N == 288) return launch<3, 18, 2>(x, w, bias, y, m, transpose_w, st);
+    if (K == 96 && N == 96) return launch<3, 6, 2>(x, w, bias, y, m, transpose_w, st);
+    if (K == 96 && N == 384) return launch<3, 24, 1>(x, w, bias, y, m, transpose_w, st);
+    if (K == 288 && N == 96) return launch<9, 6, 2>(x, w, bias, y, m, transpose_w, st);
+    if (K == 384 && N == 96) return launch<12, 6, 2>(x, w, bias, y, m, transpose_w, st);
+    if (K == 192 && N == 192) return launch<6, 12, 2>(x, w, bias, y, m, transpose_w, st);
+    return PSWIN_ERR_ARG;
+}
+
+}  // extern "C"

@@ -402,6 +402,26 @@ def colsum(x2d):
     return out
 
 
+def skinny_gemm_supported(x2d, n_out):
+    """bf16 rows x a small weight: the shapes pswin_gemm_skinny is instantiated for (stage-0 projections, stage-1 proj)"""
+    return (x2d.dtype == torch.bfloat16 and x2d.is_cuda and x2d.shape[0] >= 4096
+            and bool(_lib.load().pswin_gemm_skinny_supported(x2d.shape[1], n_out)))
+
+
+def skinny_gemm(x2d, w, bias=None, transpose_w=False):
+    """y = x2d @ W^T (+ bias) through the streaming HIP GEMM (weights resident in LDS).  transpose_w=False: w is the
+    nn.Linear weight [N, K]; transpose_w=True: w is [K, N] and y = x2d @ w (the data gradient with the same weight)."""
+    x2d = x2d.contiguous()
+    w = w.contiguous()
+    M, K = x2d.shape
+    N = w.shape[1] if transpose_w else w.shape[0]
+    y = torch.empty(M, N, dtype=torch.bfloat16, device=x2d.device)
+    b = None if bias is None else bias.detach().float().contiguous()
+    call("pswin_gemm_skinny", x2d, ptr(x2d), ptr(w), ptr(b), ptr(y), M, K, N, int(transpose_w),
+         algo_bytes=2 * M * (K + N))
+    return y
+
+
 class _BiasGelu(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, bias):

@@ -430,3 +430,24 @@ def test_layer_norm_nchw(ops, H, W, C, passthrough):
     assert torch.allclose(xd.grad.cpu(), xr.grad, rtol=1e-4, atol=1e-5)
     assert torch.allclose(gd.grad.cpu(), gr.grad, rtol=1e-4, atol=1e-4 * gr.grad.abs().max().item())
     assert torch.allclose(bd.grad.cpu(), br.grad, rtol=1e-4, atol=1e-4 * br.grad.abs().max().item())
+
+
+@pytest.mark.parametrize("K,N", [(96, 288), (96, 96), (96, 384), (288, 96), (384, 96), (192, 192)])
+@pytest.mark.parametrize("M", [4096, 5003])
+def test_skinny_gemm(ops, M, K, N):
+    """Streaming GEMM against torch: forward y = x W^T + b and the transposed-weight form dx = dy W (same bf16 operands,
+    f32 accumulation in another order, one bf16 rounding of the result)."""
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(M, K, generator=g).to(DEV).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * 0.1).to(DEV).to(torch.bfloat16)
+    b = torch.randn(N, generator=g).to(DEV)
+    assert ops.skinny_gemm_supported(x, N)
+    y = ops.skinny_gemm(x, w, b)
+    ref = x.float() @ w.float().t() + b
+    assert torch.allclose(y.float(), ref, rtol=1e-2, atol=1e-2)
+    # data-gradient form: contraction over the weight's rows
+    dy = torch.randn(M, N, generator=g).to(DEV).to(torch.bfloat16)
+    if ops._lib.load().pswin_gemm_skinny_supported(N, K):
+        dx = ops.skinny_gemm(dy, w, None, transpose_w=True)
+        assert dx.shape == (M, K)
+        assert torch.allclose(dx.float(), dy.float() @ w.float(), rtol=1e-2, atol=2e-2)
