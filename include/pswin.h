@@ -279,6 +279,17 @@ int pswin_gemm_skinny_supported(int K, int N);
 int pswin_gemm_skinny(const void* x, const void* w, const float* bias, void* y, long long M, int K, int N, int transpose_w,
                       void* stream);
 
+/* fc1 + bias + GELU of Mlp (HOT:50-57) fused into the streaming GEMM for the stage-0 shape (K = 96, N = 384):
+ *   fwd: h[M, N] = gelu(x[M, K] . W^T + bias)                        -- the pre-activation is never stored
+ *   bwd: dy = dh * gelu'(x . W^T + bias) with the pre-activation RECOMPUTED, dbias[n] = sum_m dy[m][n]
+ * (dy is then the output gradient of the fc1 GEMM: dx = dy . W and dW = dy^T x follow as for any Linear).
+ * x, w, h, dh, dy: bf16; bias, dbias: f32; workspace: f32, pswin_fc1_gelu_workspace(N) elements. */
+int pswin_fc1_gelu_supported(int K, int N);
+int pswin_fc1_gelu_fwd(const void* x, const void* w, const float* bias, void* h, long long M, int K, int N, void* stream);
+int pswin_fc1_gelu_workspace(int N);
+int pswin_fc1_gelu_bwd(const void* x, const void* w, const float* bias, const void* dh, void* dy, float* dbias,
+                       float* workspace, long long M, int K, int N, void* stream);
+
 /* Column sums of a row-major [M, N] matrix in fp32: out[n] = sum_m x[m][n] (fixed summation order).  The bias
  * gradient of every Linear on the path (autograd of nn.Linear, HOT:50-52, 236, 323) and the reduction of split-K
  * weight-gradient partials.  N % 8 == 0; workspace: f32, pswin_colsum_workspace(M, N, dtype) elements. */

@@ -57,6 +57,10 @@ _PROTOTYPES = {
     "pswin_stem_conv1_wgrad": [_vp, _vp, _vp, _vp, ctypes.c_double, _i, _vp, _vp, _vp],
     "pswin_gemm_skinny_supported": [_i, _i],
     "pswin_gemm_skinny": [_vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _i, _vp],
+    "pswin_fc1_gelu_supported": [_i, _i],
+    "pswin_fc1_gelu_fwd": [_vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _vp],
+    "pswin_fc1_gelu_workspace": [_i],
+    "pswin_fc1_gelu_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _vp],
     "pswin_bias_gelu_fwd": [_vp, _i, _vp, _vp, ctypes.c_longlong, _i, _vp],
     "pswin_bias_gelu_workspace": [ctypes.c_longlong, _i],
     "pswin_bias_gelu_tune": [_i, _i],

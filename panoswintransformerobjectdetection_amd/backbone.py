@@ -78,7 +78,14 @@ class Mlp(nn.Module):
 
     def forward_nobias2(self, x, cd):
         """fc2(gelu(fc1 x + b1)) WITHOUT fc2's bias (the caller adds it with the residual): bias + GELU in one HIP pass"""
-        return _linear(ops.bias_gelu(_linear(x, self.fc1, cd, use_bias=False), self.fc1.bias), self.fc2, cd, use_bias=False)
+        x2 = x.to(cd).reshape(-1, x.shape[-1])
+        if self.fc1.bias is not None and ops.fc1_gelu_supported(x2, self.fc1.weight.shape[0]):
+            lp = self.fc1.__dict__.get("_lowp")                    # stage 0: fc1 + bias + GELU in one streaming kernel
+            h = ops.fc1_gelu(x2, self.fc1.weight, self.fc1.bias, lp[0] if lp is not None else None)
+            h = h.view(*x.shape[:-1], h.shape[-1])
+        else:
+            h = ops.bias_gelu(_linear(x, self.fc1, cd, use_bias=False), self.fc1.bias)
+        return _linear(h, self.fc2, cd, use_bias=False)
 
 
 class WindowAttention(nn.Module, DoubleModeModule):

@@ -11,6 +11,7 @@
 // computes the data gradient dX = dY . W by staging the transposed weight (transpose done while writing the LDS image).
 // bf16 operands, f32 accumulation on v_mfma_f32_16x16x32_bf16: the arithmetic of the library path.
 #include "pswin_common.hpp"
+#include "pswin_gelu.hpp"
 
 using namespace pswin;
 
@@ -38,19 +39,55 @@ __device__ inline u32x4 pack_row8(f32x4 q0, f32x4 q1) {
     return u32x4{a0, a1, b0, b1};
 }
 
+// the same exchange on f32 quads (whole-vector bit casts: hipcc folds per-element casts of vector lanes)
+__device__ inline void exchange_row8(f32x4& q0, f32x4& q1) {
+    const u32x4 a = __builtin_bit_cast(u32x4, q0), b = __builtin_bit_cast(u32x4, q1);
+    unsigned a0 = a[0], a1 = a[1], a2 = a[2], a3 = a[3], b0 = b[0], b1 = b[1], b2 = b[2], b3 = b[3];
+    swap16_u32(a0, b0);
+    swap16_u32(a1, b1);
+    swap16_u32(a2, b2);
+    swap16_u32(a3, b3);
+    q0 = __builtin_bit_cast(f32x4, u32x4{a0, a1, a2, a3});
+    q1 = __builtin_bit_cast(f32x4, u32x4{b0, b1, b2, b3});
+}
+template <int CTRL>
+__device__ inline float dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ inline float row16_sum(float v) {   // over the 16 lanes of a group
+    v = dpp_add<0xB1>(v);
+    v = dpp_add<0x4E>(v);
+    v = dpp_add<0x141>(v);
+    return dpp_add<0x140>(v);
+}
+
+// Epilogues.  EPI 0: y = acc + bias.  EPI 1: y = gelu(acc + bias) -- fc1 + bias + nn.GELU (HOT:50-57) in one pass, the
+// pre-activation is never stored.  EPI 2 (backward of EPI 1): the pre-activation is RECOMPUTED (K = 96: cheaper than
+// storing and re-reading 201 MB), y = aux * gelu'(acc + bias) with aux = dL/d gelu-output, and the per-column sums of
+// y (the fc1 bias gradient) are accumulated per workgroup into `partial` [gridDim.x][N] (fixed order).
 // KS = K / 32 contraction steps, NT = N / 16 output-column tiles (even), RT = 16-row tiles per wave iteration
-template <int KS, int NT, int RT>
+template <int KS, int NT, int RT, int EPI>
 __global__ __launch_bounds__(THREADS, 2) void skinny_gemm_kernel(const void* __restrict__ x, const void* __restrict__ w,
                                                                  const float* __restrict__ bias, void* __restrict__ y,
-                                                                 int M, int transpose_w) {
-    constexpr int K = 32 * KS, N = 16 * NT, LD = 2 * K + 16;           // LDS row stride in bytes
+                                                                 int M, int transpose_w, const void* __restrict__ aux,
+                                                                 float* __restrict__ partial) {
+    constexpr int K = 32 * KS, N = 16 * NT;
+    // LDS row stride in bytes.  K = 96: dense 192-byte rows with the 16-byte chunk XOR-swizzled inside its group of 4 by
+    // row bits 1-2 (keeps the largest image, 384 x 96, at 72 KB so that two workgroups fit a CU); otherwise 16 bytes
+    // of padding.  Both make the 16-byte reads of 8 consecutive rows conflict-free.
+    constexpr int LD = (K == 96) ? 192 : 2 * K + 16;
+    auto woff = [](int row, int chunk) {
+        if constexpr (K == 96) return row * 192 + ((((chunk & ~3) | ((chunk ^ (row >> 1)) & 3))) << 4);
+        else return row * LD + chunk * 16;
+    };
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* wl = smem;                                                     // [N][LD]
     float* bl = reinterpret_cast<float*>(smem + N * LD);                 // [N]
+    float* cs = bl + N;                                                  // EPI 2: [4 waves][N] column sums
     if (!transpose_w) {                                                  // w: [N][K] (nn.Linear layout)
         for (int i = threadIdx.x; i < N * (K / 8); i += THREADS) {
             const int row = i / (K / 8), ch = i - row * (K / 8);
-            *reinterpret_cast<u32x4*>(wl + row * LD + ch * 16) = reinterpret_cast<const u32x4*>(w)[i];
+            *reinterpret_cast<u32x4*>(wl + woff(row, ch)) = reinterpret_cast<const u32x4*>(w)[i];
         }
     } else {                                                             // w: [K][N] -> image[n][k]
         const unsigned short* ws = reinterpret_cast<const unsigned short*>(w);
@@ -59,18 +96,21 @@ __global__ __launch_bounds__(THREADS, 2) void skinny_gemm_kernel(const void* __r
             const u32x4 v = *reinterpret_cast<const u32x4*>(ws + (size_t)k * N + n0);
 #pragma unroll
             for (int d = 0; d < 4; ++d) {
-                *reinterpret_cast<unsigned short*>(wl + (n0 + 2 * d) * LD + 2 * k) = (unsigned short)(v[d] & 0xffffu);
-                *reinterpret_cast<unsigned short*>(wl + (n0 + 2 * d + 1) * LD + 2 * k) = (unsigned short)(v[d] >> 16);
+                *reinterpret_cast<unsigned short*>(wl + woff(n0 + 2 * d, k >> 3) + 2 * (k & 7)) = (unsigned short)(v[d] & 0xffffu);
+                *reinterpret_cast<unsigned short*>(wl + woff(n0 + 2 * d + 1, k >> 3) + 2 * (k & 7)) = (unsigned short)(v[d] >> 16);
             }
         }
     }
     for (int i = threadIdx.x; i < N; i += THREADS) bl[i] = bias ? bias[i] : 0.f;
+    if constexpr (EPI == 2)
+        for (int i = threadIdx.x; i < 4 * N; i += THREADS) cs[i] = 0.f;
     __syncthreads();
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int c = lane & 15, g = lane >> 4;
     const rsrc_t xs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(x), 0, (int)((size_t)M * K * 2), 0x00020000);
     const rsrc_t ys = __builtin_amdgcn_make_buffer_rsrc(y, 0, (int)((size_t)M * N * 2), 0x00020000);
+    const rsrc_t as = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(aux), 0, EPI == 2 ? (int)((size_t)M * N * 2) : 0, 0x00020000);
     constexpr int ROWS = 16 * RT;
     const int ntiles = (M + ROWS - 1) / ROWS;
     const int d0 = 8 * (g >> 1) + 16 * (g & 1);
@@ -104,7 +144,7 @@ __global__ __launch_bounds__(THREADS, 2) void skinny_gemm_kernel(const void* __r
             const int s_ = bi / (NT / BT), nt0 = (bi - s_ * (NT / BT)) * BT;
 #pragma unroll
             for (int j = 0; j < BT; ++j)
-                dst[j] = *reinterpret_cast<const bf16x8*>(wl + (16 * (nt0 + j) + c) * LD + (32 * s_ + 8 * g) * 2);
+                dst[j] = *reinterpret_cast<const bf16x8*>(wl + woff(16 * (nt0 + j) + c, 4 * s_ + g));
         };
         read_batch(0, a[0]);
 #pragma unroll
@@ -126,26 +166,68 @@ __global__ __launch_bounds__(THREADS, 2) void skinny_gemm_kernel(const void* __r
             for (int np = 0; np < NT / 2; ++np) {
                 const f32x4 b0 = *reinterpret_cast<const f32x4*>(bl + 32 * np + 4 * g);
                 const f32x4 b1 = *reinterpret_cast<const f32x4*>(bl + 32 * np + 16 + 4 * g);
-                const u32x4 v = pack_row8(acc[rt][2 * np] + b0, acc[rt][2 * np + 1] + b1);
-                __builtin_amdgcn_raw_buffer_store_b128(v, ys, base == 0xFFFFFF00u ? base : base + 64u * np, 0, 0);
+                f32x4 q0 = acc[rt][2 * np] + b0, q1 = acc[rt][2 * np + 1] + b1;
+                const unsigned off = base == 0xFFFFFF00u ? base : base + 64u * np;
+                if constexpr (EPI == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        q0[e] = gelu_f(q0[e]);
+                        q1[e] = gelu_f(q1[e]);
+                    }
+                }
+                if constexpr (EPI == 2) {
+                    // 8 consecutive columns 32 np + d0 .. of this lane's row, the layout of the 16-byte aux load
+                    exchange_row8(q0, q1);
+                    const u32x4 dh = __builtin_amdgcn_raw_buffer_load_b128(as, off, 0, 0);     // rows >= M: zeros
+                    float v[8];
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const float g0 = gelu_grad_f(d < 2 ? q0[2 * d] : q1[2 * d - 4]);
+                        const float g1 = gelu_grad_f(d < 2 ? q0[2 * d + 1] : q1[2 * d - 3]);
+                        v[2 * d] = __builtin_bit_cast(float, dh[d] << 16) * g0;
+                        v[2 * d + 1] = __builtin_bit_cast(float, dh[d] & 0xffff0000u) * g1;
+                    }
+                    const u32x4 o = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+                    __builtin_amdgcn_raw_buffer_store_b128(o, ys, off, 0, 0);
+                    // column sums over the 16 rows of the tile (lanes c of a group share the columns), then one lane per
+                    // group adds them to this wave's LDS row: the kernel is HBM bound, the VALU has the slack
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float sum = row16_sum(v[j]);
+                        if (c == 0) cs[wave * N + 32 * np + d0 + j] += sum;
+                    }
+                } else {
+                    __builtin_amdgcn_raw_buffer_store_b128(pack_row8(q0, q1), ys, off, 0, 0);
+                }
             }
         }
     }
+    if constexpr (EPI == 2) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < N; i += THREADS)
+            partial[(size_t)blockIdx.x * N + i] = (cs[i] + cs[N + i]) + (cs[2 * N + i] + cs[3 * N + i]);
+    }
 }
 
-template <int KS, int NT, int RT>
-int launch(const void* x, const void* w, const float* bias, void* y, int M, int transpose_w, hipStream_t st) {
+constexpr int MAX_GRID = 512;                    // 2 workgroups per CU, persistent over the row tiles
+
+template <int KS, int NT, int RT, int EPI>
+int launch(const void* x, const void* w, const float* bias, void* y, int M, int transpose_w, const void* aux, float* partial,
+           hipStream_t st, int* grid_out = nullptr) {
     constexpr int K = 32 * KS, N = 16 * NT;
-    constexpr size_t lds = (size_t)N * (2 * K + 16) + N * sizeof(float);
+    constexpr size_t lds = (size_t)N * (K == 96 ? 192 : 2 * K + 16) + N * sizeof(float) * (EPI == 2 ? 5 : 1);
     static bool configured = false;
     if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_gemm_kernel<KS, NT, RT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_gemm_kernel<KS, NT, RT, EPI>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         configured = true;
     }
     const int ntiles = (M + 16 * RT - 1) / (16 * RT);
     int grid = (ntiles + 3) / 4;
-    if (grid > 512) grid = 512;                       // 2 workgroups per CU, persistent over the row tiles
-    hipLaunchKernelGGL((skinny_gemm_kernel<KS, NT, RT>), dim3(grid), dim3(THREADS), lds, st, x, w, bias, y, M, transpose_w);
+    if (grid > MAX_GRID) grid = MAX_GRID;
+    if (grid_out) *grid_out = grid;
+    hipLaunchKernelGGL((skinny_gemm_kernel<KS, NT, RT, EPI>), dim3(grid), dim3(THREADS), lds, st, x, w, bias, y, M, transpose_w,
+                       aux, partial);
     PSWIN_LAUNCH_RET();
 }
 
@@ -164,13 +246,35 @@ int pswin_gemm_skinny(const void* x, const void* w, const float* bias, void* y, 
     PSWIN_CHECK_ARG(M * (long long)(K > N ? K : N) * 2 < 0xFFFFFF00ll && aligned16(x) && aligned16(w) && aligned16(y));
     hipStream_t st = (hipStream_t)stream;
     const int m = (int)M;
-    if (K == 96 && N == 288) return launch<3, 18, 2>(x, w, bias, y, m, transpose_w, st);
-    if (K == 96 && N == 96) return launch<3, 6, 2>(x, w, bias, y, m, transpose_w, st);
-    if (K == 96 && N == 384) return launch<3, 24, 1>(x, w, bias, y, m, transpose_w, st);
-    if (K == 288 && N == 96) return launch<9, 6, 2>(x, w, bias, y, m, transpose_w, st);
-    if (K == 384 && N == 96) return launch<12, 6, 2>(x, w, bias, y, m, transpose_w, st);
-    if (K == 192 && N == 192) return launch<6, 12, 2>(x, w, bias, y, m, transpose_w, st);
+    if (K == 96 && N == 288) return launch<3, 18, 2, 0>(x, w, bias, y, m, transpose_w, nullptr, nullptr, st);
+    if (K == 96 && N == 96) return launch<3, 6, 2, 0>(x, w, bias, y, m, transpose_w, nullptr, nullptr, st);
+    if (K == 96 && N == 384) return launch<3, 24, 1, 0>(x, w, bias, y, m, transpose_w, nullptr, nullptr, st);
+    if (K == 288 && N == 96) return launch<9, 6, 2, 0>(x, w, bias, y, m, transpose_w, nullptr, nullptr, st);
+    if (K == 384 && N == 96) return launch<12, 6, 2, 0>(x, w, bias, y, m, transpose_w, nullptr, nullptr, st);
+    if (K == 192 && N == 192) return launch<6, 12, 2, 0>(x, w, bias, y, m, transpose_w, nullptr, nullptr, st);
     return PSWIN_ERR_ARG;
+}
+
+/* fc1 + bias + GELU of the stage-0 Mlp (K = 96, N = 384) */
+int pswin_fc1_gelu_supported(int K, int N) { return K == 96 && N == 384; }
+
+int pswin_fc1_gelu_fwd(const void* x, const void* w, const float* bias, void* h, long long M, int K, int N, void* stream) {
+    PSWIN_CHECK_ARG(x && w && h && M > 0 && pswin_fc1_gelu_supported(K, N));
+    PSWIN_CHECK_ARG(M * (long long)N * 2 < 0xFFFFFF00ll && aligned16(x) && aligned16(w) && aligned16(h));
+    return launch<3, 24, 1, 1>(x, w, bias, h, (int)M, 0, nullptr, nullptr, (hipStream_t)stream);
+}
+
+int pswin_fc1_gelu_workspace(int N) { return N > 0 ? MAX_GRID * N : PSWIN_ERR_ARG; }
+
+int pswin_fc1_gelu_bwd(const void* x, const void* w, const float* bias, const void* dh, void* dy, float* dbias,
+                       float* workspace, long long M, int K, int N, void* stream) {
+    PSWIN_CHECK_ARG(x && w && dh && dy && dbias && workspace && M > 0 && pswin_fc1_gelu_supported(K, N));
+    PSWIN_CHECK_ARG(M * (long long)N * 2 < 0xFFFFFF00ll && aligned16(x) && aligned16(w) && aligned16(dh) && aligned16(dy));
+    int grid = 0;
+    const int rc = launch<3, 24, 1, 2>(x, w, bias, dy, (int)M, 0, dh, workspace, (hipStream_t)stream, &grid);
+    if (rc) return rc;
+    launch_colsum(workspace, grid, N, dbias, (hipStream_t)stream);
+    PSWIN_LAUNCH_RET();
 }
 
 }  // extern "C"

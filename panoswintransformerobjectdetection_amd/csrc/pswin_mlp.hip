@@ -9,6 +9,7 @@
 // bf16 rounding of dy), reduced per block through LDS and finished by the fixed-order column sum.
 // A thread owns one 16-byte channel group; a block covers GW groups x RPS rows per step and strides over the rows.
 #include "pswin_common.hpp"
+#include "pswin_gelu.hpp"
 
 using namespace pswin;
 
@@ -16,34 +17,6 @@ namespace {
 
 constexpr int THREADS = 256;
 int g_unr_fwd = 2, g_unr_bwd = 4;             // row steps per block (pswin_bias_gelu_tune)
-
-// Phi(v) = 0.5 (1 + erf(v / sqrt 2)) and E = exp(-v^2 / 2).  The GELU kernels are VALU bound with libm's erff / expf
-// (~50 instructions per element: 100 M elements of a stage-0 block take 150 us of pure ALU time, the memory traffic
-// 100 us), so erf uses Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, i.e. f32 rounding level) on the hardware
-// reciprocal and exp2, sharing ONE exponential with the density term of the derivative:
-//   erf(z) = 1 - (a1 t + a2 t^2 + a3 t^3 + a4 t^4 + a5 t^5) exp(-z^2),  t = 1 / (1 + p z),  z = |v| / sqrt 2 >= 0
-// and the lower tail is formed directly (0.5 poly E, no 1 - erf cancellation).
-__device__ inline void phi_and_exp(float v, float& cdf, float& E) {
-    const float z = fabsf(v) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(0.3275911f, z, 1.0f));
-    E = __builtin_amdgcn_exp2f(v * v * -0.72134752044448170368f);            // exp(-v^2 / 2)
-    float p = __builtin_fmaf(1.061405429f, t, -1.453152027f);
-    p = __builtin_fmaf(p, t, 1.421413741f);
-    p = __builtin_fmaf(p, t, -0.284496736f);
-    p = __builtin_fmaf(p, t, 0.254829592f);
-    const float tail = 0.5f * p * t * E;                                        // 0.5 erfc(z)
-    cdf = v >= 0.f ? 1.0f - tail : tail;
-}
-__device__ inline float gelu_f(float v) {
-    float cdf, E;
-    phi_and_exp(v, cdf, E);
-    return v * cdf;
-}
-__device__ inline float gelu_grad_f(float v) {
-    float cdf, E;
-    phi_and_exp(v, cdf, E);
-    return __builtin_fmaf(v * 0.39894228040143267794f, E, cdf);
-}
 
 template <int DT>
 struct Vec {

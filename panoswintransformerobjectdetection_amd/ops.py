@@ -422,6 +422,54 @@ def skinny_gemm(x2d, w, bias=None, transpose_w=False):
     return y
 
 
+class _Fc1Gelu(torch.autograd.Function):
+    """h = gelu(x W1^T + b1) for the stage-0 Mlp in ONE streaming pass (pswin_fc1_gelu_fwd); the backward pass recomputes
+    the pre-activation (K = 96) instead of storing it: dy = dh gelu'(.), db1 = column sums of dy, dx = dy W1 (streaming
+    GEMM), dW1 = dy^T x (library batched GEMM over row chunks + fixed-order column sum)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, w_lp):
+        wb = w_lp if w_lp is not None else weight.to(x.dtype)
+        x = x.contiguous()
+        M, K = x.shape
+        N = wb.shape[0]
+        h = torch.empty(M, N, dtype=x.dtype, device=x.device)
+        b = bias.detach().float().contiguous()
+        call("pswin_fc1_gelu_fwd", x, ptr(x), ptr(wb), ptr(b), ptr(h), M, K, N, algo_bytes=2 * M * (K + N))
+        ctx.save_for_backward(x, wb, b)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        x, wb, b = ctx.saved_tensors
+        M, K = x.shape
+        N = wb.shape[0]
+        dh = dh.to(x.dtype).contiguous()
+        dy = torch.empty_like(dh)
+        db = torch.empty(N, dtype=torch.float32, device=x.device)
+        ws = torch.empty(_lib.load().pswin_fc1_gelu_workspace(N), dtype=torch.float32, device=x.device)
+        call("pswin_fc1_gelu_bwd", x, ptr(x), ptr(wb), ptr(b), ptr(dh), ptr(dy), ptr(db), ptr(ws), M, K, N,
+             algo_bytes=2 * M * (K + 2 * N))
+        dx = skinny_gemm(dy, wb, None, transpose_w=True) if ctx.needs_input_grad[0] else None
+        from .backbone import _pick_split
+        ch = _pick_split(M, -(-N // 64) * -(-K // 64))
+        if ch > 1:
+            part = torch.bmm(dy.view(ch, M // ch, N).transpose(1, 2), x.view(ch, M // ch, K))
+            dw = colsum(part.view(ch, N * K)).view(N, K)
+        else:
+            dw = (dy.t() @ x).float()
+        return dx, dw, db, None
+
+
+def fc1_gelu_supported(x2d, n_out):
+    return (x2d.dtype == torch.bfloat16 and x2d.is_cuda and x2d.shape[0] >= 4096
+            and bool(_lib.load().pswin_fc1_gelu_supported(x2d.shape[1], n_out)))
+
+
+def fc1_gelu(x2d, weight, bias, w_lp=None):
+    return _Fc1Gelu.apply(x2d, weight, bias, w_lp)
+
+
 class _BiasGelu(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, bias):

@@ -451,3 +451,28 @@ def test_skinny_gemm(ops, M, K, N):
         dx = ops.skinny_gemm(dy, w, None, transpose_w=True)
         assert dx.shape == (M, K)
         assert torch.allclose(dx.float(), dy.float() @ w.float(), rtol=1e-2, atol=2e-2)
+
+
+@pytest.mark.parametrize("M", [4096, 5003])
+def test_fc1_gelu_fused(ops, M):
+    """fc1 + bias + GELU in the streaming GEMM and its recompute backward against torch (bf16 operands, f32 math)."""
+    K, N = 96, 384
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(M, K, generator=g).to(DEV).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * 0.15).to(DEV)
+    b = (torch.randn(N, generator=g) * 0.3).to(DEV)
+    gh = torch.randn(M, N, generator=g).to(DEV).to(torch.bfloat16)
+    xr = x.float().clone().requires_grad_(True)
+    wr = w.to(torch.bfloat16).float().clone().requires_grad_(True)
+    br = b.clone().requires_grad_(True)
+    ref = F.gelu(xr @ wr.t() + br)
+    (ref * gh.float()).sum().backward()
+    xd = x.clone().requires_grad_(True)
+    wd, bd = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    assert ops.fc1_gelu_supported(xd, N)
+    h = ops.fc1_gelu(xd, wd, bd)
+    h.backward(gh)
+    assert torch.allclose(h.float(), ref, rtol=1e-2, atol=1e-2)
+    assert torch.allclose(xd.grad.float(), xr.grad, rtol=2e-2, atol=2e-2)
+    rel = lambda a, r: float((a - r).norm() / r.norm())
+    assert rel(wd.grad, wr.grad) < 1e-2 and rel(bd.grad, br.grad) < 1e-2
