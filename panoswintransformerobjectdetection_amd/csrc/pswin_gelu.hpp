@@ -32,4 +32,33 @@ __device__ inline float gelu_grad_f(float v) {
     return __builtin_fmaf(v * 0.39894228040143267794f, E, cdf);
 }
 
+// Two elements at a time on packed-f32 VALU instructions (v_pk_mul_f32 / v_pk_fma_f32): the polynomial and the scalings
+// take half the issue slots; the reciprocal and the exponential stay scalar (transcendental unit).  Used by the kernels
+// whose epilogue is VALU bound (the fused fc1 + GELU streaming GEMM).
+typedef __attribute__((ext_vector_type(2))) float gelu_f32x2;
+__device__ inline void phi_and_exp2(gelu_f32x2 v, gelu_f32x2& cdf, gelu_f32x2& E) {
+    const gelu_f32x2 az = {fabsf(v[0]), fabsf(v[1])};
+    const gelu_f32x2 den = __builtin_elementwise_fma(az, gelu_f32x2{0.3275911f * 0.70710678118654752440f, 0.3275911f * 0.70710678118654752440f},
+                                                     gelu_f32x2{1.0f, 1.0f});
+    const gelu_f32x2 t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+    const gelu_f32x2 ex = v * v * gelu_f32x2{-0.72134752044448170368f, -0.72134752044448170368f};
+    E = gelu_f32x2{__builtin_amdgcn_exp2f(ex[0]), __builtin_amdgcn_exp2f(ex[1])};
+    gelu_f32x2 p = __builtin_elementwise_fma(gelu_f32x2{1.061405429f, 1.061405429f}, t, gelu_f32x2{-1.453152027f, -1.453152027f});
+    p = __builtin_elementwise_fma(p, t, gelu_f32x2{1.421413741f, 1.421413741f});
+    p = __builtin_elementwise_fma(p, t, gelu_f32x2{-0.284496736f, -0.284496736f});
+    p = __builtin_elementwise_fma(p, t, gelu_f32x2{0.254829592f, 0.254829592f});
+    const gelu_f32x2 tail = p * t * E * gelu_f32x2{0.5f, 0.5f};
+    cdf = gelu_f32x2{v[0] >= 0.f ? 1.0f - tail[0] : tail[0], v[1] >= 0.f ? 1.0f - tail[1] : tail[1]};
+}
+__device__ inline gelu_f32x2 gelu_f2(gelu_f32x2 v) {
+    gelu_f32x2 cdf, E;
+    phi_and_exp2(v, cdf, E);
+    return v * cdf;
+}
+__device__ inline gelu_f32x2 gelu_grad_f2(gelu_f32x2 v) {
+    gelu_f32x2 cdf, E;
+    phi_and_exp2(v, cdf, E);
+    return __builtin_elementwise_fma(v * gelu_f32x2{0.39894228040143267794f, 0.39894228040143267794f}, E, cdf);
+}
+
 }  // namespace pswin

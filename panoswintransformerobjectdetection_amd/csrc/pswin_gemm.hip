@@ -170,9 +170,10 @@ __global__ __launch_bounds__(THREADS, 2) void skinny_gemm_kernel(const void* __r
                 const unsigned off = base == 0xFFFFFF00u ? base : base + 64u * np;
                 if constexpr (EPI == 1) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        q0[e] = gelu_f(q0[e]);
-                        q1[e] = gelu_f(q1[e]);
+                    for (int e = 0; e < 4; e += 2) {
+                        const gelu_f32x2 a = gelu_f2(gelu_f32x2{q0[e], q0[e + 1]}), b = gelu_f2(gelu_f32x2{q1[e], q1[e + 1]});
+                        q0[e] = a[0]; q0[e + 1] = a[1];
+                        q1[e] = b[0]; q1[e + 1] = b[1];
                     }
                 }
                 if constexpr (EPI == 2) {
@@ -182,10 +183,10 @@ __global__ __launch_bounds__(THREADS, 2) void skinny_gemm_kernel(const void* __r
                     float v[8];
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {
-                        const float g0 = gelu_grad_f(d < 2 ? q0[2 * d] : q1[2 * d - 4]);
-                        const float g1 = gelu_grad_f(d < 2 ? q0[2 * d + 1] : q1[2 * d - 3]);
-                        v[2 * d] = __builtin_bit_cast(float, dh[d] << 16) * g0;
-                        v[2 * d + 1] = __builtin_bit_cast(float, dh[d] & 0xffff0000u) * g1;
+                        const gelu_f32x2 yy = d < 2 ? gelu_f32x2{q0[2 * d], q0[2 * d + 1]} : gelu_f32x2{q1[2 * d - 4], q1[2 * d - 3]};
+                        const gelu_f32x2 gg = gelu_grad_f2(yy);
+                        v[2 * d] = __builtin_bit_cast(float, dh[d] << 16) * gg[0];
+                        v[2 * d + 1] = __builtin_bit_cast(float, dh[d] & 0xffff0000u) * gg[1];
                     }
                     const u32x4 o = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
                     __builtin_amdgcn_raw_buffer_store_b128(o, ys, off, 0, 0);
