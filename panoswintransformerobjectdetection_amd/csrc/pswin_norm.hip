@@ -471,8 +471,12 @@ int launch_bwd(int L, const void* dy, const int32_t* inv, const void* x, const R
                long long rows, int C, int blocks, hipStream_t st) {
 #define PSWIN_LN_BWD(LL)                                                                                                \
     case LL:                                                                                                            \
-        hipLaunchKernelGGL((ln_bwd_kernel<MODE, DYDT, XDT, LL, 4, RSUM>), dim3(blocks), dim3(THREADS), 0, st, dy, inv, \
-                           x, rs, mean, rstd, gamma, dx, dres, res_scale, part, rows, C);                               \
+        if (C / 4 <= 3 * LL)      /* 3 chunks per lane (C = 96, 192, 384, 768): 20 registers less, 4 waves per SIMD */      \
+            hipLaunchKernelGGL((ln_bwd_kernel<MODE, DYDT, XDT, LL, 3, RSUM>), dim3(blocks), dim3(THREADS), 0, st, dy, inv, \
+                               x, rs, mean, rstd, gamma, dx, dres, res_scale, part, rows, C);                           \
+        else                                                                                                            \
+            hipLaunchKernelGGL((ln_bwd_kernel<MODE, DYDT, XDT, LL, 4, RSUM>), dim3(blocks), dim3(THREADS), 0, st, dy, inv, \
+                               x, rs, mean, rstd, gamma, dx, dres, res_scale, part, rows, C);                           \
         break;
     if (wide_row(C)) {
         hipLaunchKernelGGL((ln_bwd_kernel<MODE, DYDT, XDT, 64, 8, RSUM>), dim3(blocks), dim3(THREADS), 0, st, dy, inv, x, rs,
