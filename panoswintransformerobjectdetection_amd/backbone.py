@@ -10,8 +10,10 @@ What runs where: every data-layout step of a block (LayerNorm-ed features -> pan
 partition, and the way back with crop, DropPath and the residual add) is one indexed row-copy kernel; the
 7x7 attention core (q.k^T, great-circle + relative-position bias, mask, softmax, .v) is one MFMA kernel per
 direction; PatchMerging's gather and the pitch module's two static bilinear resamplings are row kernels too
-(include/pswin.h).  Dense projections (qkv / proj / MLP / reduction), LayerNorm, GELU and the PatchEmbed
-convolutions go through PyTorch-ROCm (hipBLASLt / MIOpen).  uv coordinates never ride as feature channels
+(include/pswin.h).  LayerNorm (fused with the gather / the residual accumulation / the NCHW output), bias + GELU, the
+bf16 PatchEmbed stem and the Linear layers of the high-resolution stage run in HIP kernels as well (ops.py, stem.py);
+the remaining dense projections and every weight gradient are hipBLASLt GEMMs through PyTorch-ROCm, the fp32 parity
+configuration of PatchEmbed uses MIOpen convolutions.  uv coordinates never ride as feature channels
 (the reference's C+2 layout, HOT:964): they are a function of position, so the great-circle tables are cached
 per shape.
 
@@ -383,7 +385,9 @@ class _ChannelBias(torch.autograd.Function):
 
 
 class PatchEmbed(nn.Module):
-    """HOT:727-773 (convolutions through MIOpen; channels-last so that the token layout needs no transpose)."""
+    """HOT:727-773.  bf16 compute on the default geometry (3 -> 32 -> 64 -> 96, patch 4): the fused HIP stem
+    (stem.py / csrc/pswin_stem.hip).  Otherwise (fp32 parity configuration, other widths, an image that needs a
+    gradient): MIOpen convolutions, channels-last so that the token layout needs no transpose, + the HIP BN/ReLU kernels."""
 
     def __init__(self, patch_size=4, in_chans=3, embed_dim=96, norm=True):
         super().__init__()
