@@ -19,10 +19,21 @@ namespace {
 
 constexpr int THREADS = 256;
 
+// Sum over the L lanes of a row (every lane receives it).  Steps inside a 16-lane DPP row run on the VALU
+// (v_add_f32 with a DPP modifier, ~5 cycles): __shfl_xor compiles to ds_bpermute_b32, an LDS-crossbar round trip of
+// ~100+ cycles each, and the 2 x log2(L) dependent ones per row were a quarter of a LayerNorm backward iteration.
+template <int CTRL>
+__device__ inline float dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
 template <int L>
 __device__ inline float row_sum(float v) {
-#pragma unroll
-    for (int off = L / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    if constexpr (L >= 2) v = dpp_add<0xB1>(v);      // quad_perm [1,0,3,2]: lane ^ 1
+    if constexpr (L >= 4) v = dpp_add<0x4E>(v);      // quad_perm [2,3,0,1]: lane ^ 2
+    if constexpr (L >= 8) v = dpp_add<0x141>(v);     // row_half_mirror: the other quad of the 8 (quads are uniform by now)
+    if constexpr (L >= 16) v = dpp_add<0x140>(v);    // row_mirror: the other half of the 16
+    if constexpr (L >= 32) v += __shfl_xor(v, 16);
+    if constexpr (L >= 64) v += __shfl_xor(v, 32);
     return v;
 }
 
