@@ -152,6 +152,12 @@ int pswin_ln_nchw_bwd(const float* dy, const float* x, const float* mean, const 
 /* Workspace elements for the LayerNorm backward kernels over `rows` walked rows of width C. */
 int pswin_ln_workspace(long long rows, int C);
 
+/* The three LayerNorm backward entry points accept dgamma == dbeta == NULL ("partial rows only"): the kernel leaves
+ * pswin_ln_partial_rows(rows, C) rows of [dgamma(C) | dbeta(C)] (or [dgamma | dbeta | dres_sum] when dres_sum != NULL;
+ * dres_sum is then only a flag and is not written) in `workspace`, and the caller sums them later, typically together
+ * with every other parameter-gradient reduction of the backward pass through pswin_reduce_jobs. */
+int pswin_ln_partial_rows(long long rows, int C);
+
 /* PatchMerging gather fused with its LayerNorm(4C) (HOT:563-574): y[b][i*W2+j] = LN(concat of the 4 tokens).
  * x: [B, H*W, C]; y: [B, H2*W2, 4C]; gamma, beta: f32 [4C]; mean, rstd: f32 [B, H2*W2]; C % 16 == 0, 4C <= 2048. */
 int pswin_ln_patch_merge_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, float eps, void* y,
@@ -248,6 +254,7 @@ int pswin_stem_conv2_bwd(const void* x4, const void* w1p, const float* prm, cons
 int pswin_bias_gelu_fwd(const void* y, int dtype, const float* bias, void* h, long long M, int N, void* stream);
 int pswin_bias_gelu_workspace(long long M, int N);
 int pswin_bias_gelu_tune(int unr_fwd, int unr_bwd);   /* rows steps per block of the two kernels: 1, 2 or 4 (default 2, 4) */
+int pswin_bias_gelu_partial_rows(long long M, int N, int dtype);   /* rows of N sums left in workspace when dbias == NULL */
 int pswin_bias_gelu_bwd(const void* dh, const void* y, int dtype, const float* bias, void* dy, float* dbias,
                         float* workspace, long long M, int N, void* stream);
 
@@ -287,6 +294,7 @@ int pswin_gemm_skinny(const void* x, const void* w, const float* bias, void* y, 
 int pswin_fc1_gelu_supported(int K, int N);
 int pswin_fc1_gelu_fwd(const void* x, const void* w, const float* bias, void* h, long long M, int K, int N, void* stream);
 int pswin_fc1_gelu_workspace(int N);
+int pswin_fc1_gelu_partial_rows(long long M);                      /* rows of N sums left in workspace when dbias == NULL */
 int pswin_fc1_gelu_bwd(const void* x, const void* w, const float* bias, const void* dh, void* dy, float* dbias,
                        float* workspace, long long M, int K, int N, void* stream);
 
@@ -295,6 +303,24 @@ int pswin_fc1_gelu_bwd(const void* x, const void* w, const float* bias, const vo
  * weight-gradient partials.  N % 8 == 0; workspace: f32, pswin_colsum_workspace(M, N, dtype) elements. */
 int pswin_colsum_workspace(long long M, int N, int dtype);
 int pswin_colsum(const void* x, int dtype, long long M, int N, float* out, float* workspace, void* stream);
+/* out == NULL: first stage only; pswin_colsum_workspace(M, N, dtype) / N partial rows of N sums stay in workspace. */
+
+/* Grouped column sums: dst[c] = sum_{r < rows} src[r * ld + c], c < cols, for up to a few hundred independent jobs in
+ * ONE launch per 96 jobs (fixed summation order, bitwise reproducible).  The autograd of the path produces ~120 small
+ * parameter-gradient reductions per backward pass (split-K partials of dW = dY^T X, bias-gradient partial rows, the
+ * LayerNorm dgamma / dbeta rows; reference: torch autograd of HOT:50-58, 236, 323, 503, 512); none of them is needed
+ * before the pass ends, so the host queues them and issues them here together.  `jobs` is a HOST array (it is copied
+ * into the kernel arguments, so it may be freed on return and a captured hipGraph keeps its own copy).
+ * src: f32 or bf16 (dtype), 16-byte aligned, ld % 8 == 0 (bf16) / % 4 == 0 (f32); cols likewise; dst: f32, aligned. */
+typedef struct pswin_reduce_job {
+    const void* src;
+    float* dst;
+    int dtype;
+    int rows;
+    int cols;
+    int ld;
+} pswin_reduce_job;
+int pswin_reduce_jobs(const pswin_reduce_job* jobs, int n_jobs, void* stream);
 
 /* Static 4-tap row interpolation (the two F.grid_sample calls of PitchAttentionModule.get_rotated,
  * HOT:1038, 1090, with input-independent grids; lzx/pano_rotate.py:169-187):

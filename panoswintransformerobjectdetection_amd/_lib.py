@@ -67,6 +67,10 @@ _PROTOTYPES = {
     "pswin_bias_gelu_bwd": [_vp, _vp, _i, _vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _vp],
     "pswin_colsum_workspace": [ctypes.c_longlong, _i, _i],
     "pswin_colsum": [_vp, _i, ctypes.c_longlong, _i, _vp, _vp, _vp],
+    "pswin_reduce_jobs": [_vp, _i, _vp],
+    "pswin_ln_partial_rows": [ctypes.c_longlong, _i],
+    "pswin_bias_gelu_partial_rows": [ctypes.c_longlong, _i, _i],
+    "pswin_fc1_gelu_partial_rows": [ctypes.c_longlong],
     "pswin_interp_rows": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "pswin_interp_rows_adjoint": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "pswin_attn_pad_tiles": [_vp, _i, _i, _vp, _vp],
@@ -83,6 +87,12 @@ _lib = None
 
 class PswinError(RuntimeError):
     pass
+
+
+class ReduceJob(ctypes.Structure):
+    """pswin_reduce_job of include/pswin.h"""
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("dtype", ctypes.c_int), ("rows", ctypes.c_int),
+                ("cols", ctypes.c_int), ("ld", ctypes.c_int)]
 
 
 def exported_symbols():

@@ -155,7 +155,7 @@ class _LinearSplitK(torch.autograd.Function):
         ch = _pick_split(M, -(-N // 64) * -(-K // 64))
         if ch > 1:
             part = torch.bmm(dy.view(ch, M // ch, N).transpose(1, 2), x.view(ch, M // ch, K))
-            dw = ops.colsum(part.view(ch, N * K)).view(N, K)
+            dw = ops.sum_rows(part, ch, N * K).view(N, K)
         else:
             dw = (dy.t() @ x).float()
         db = ops.colsum(dy) if ctx.has_bias else None

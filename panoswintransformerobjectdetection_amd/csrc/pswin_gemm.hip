@@ -269,13 +269,20 @@ int pswin_fc1_gelu_workspace(int N) { return N > 0 ? MAX_GRID * N : PSWIN_ERR_AR
 
 int pswin_fc1_gelu_bwd(const void* x, const void* w, const float* bias, const void* dh, void* dy, float* dbias,
                        float* workspace, long long M, int K, int N, void* stream) {
-    PSWIN_CHECK_ARG(x && w && dh && dy && dbias && workspace && M > 0 && pswin_fc1_gelu_supported(K, N));
+    PSWIN_CHECK_ARG(x && w && dh && dy && workspace && M > 0 && pswin_fc1_gelu_supported(K, N));
     PSWIN_CHECK_ARG(M * (long long)N * 2 < 0xFFFFFF00ll && aligned16(x) && aligned16(w) && aligned16(dh) && aligned16(dy));
     int grid = 0;
     const int rc = launch<3, 24, 1, 2>(x, w, bias, dy, (int)M, 0, dh, workspace, (hipStream_t)stream, &grid);
     if (rc) return rc;
-    launch_colsum(workspace, grid, N, dbias, (hipStream_t)stream);
+    if (dbias) launch_colsum(workspace, grid, N, dbias, (hipStream_t)stream);   // else: partial rows only
     PSWIN_LAUNCH_RET();
+}
+
+int pswin_fc1_gelu_partial_rows(long long M) {
+    if (M <= 0 || M > 0x7fffffffll) return PSWIN_ERR_ARG;
+    const int ntiles = (int)((M + 15) / 16);           // RT = 1 for the fused kernels
+    const int grid = (ntiles + 3) / 4;
+    return grid > MAX_GRID ? MAX_GRID : grid;
 }
 
 }  // extern "C"

@@ -189,13 +189,21 @@ int pswin_bias_gelu_workspace(long long M, int N) {
 
 int pswin_bias_gelu_bwd(const void* dh, const void* y, int dtype, const float* bias, void* dy, float* dbias,
                         float* workspace, long long M, int N, void* stream) {
-    PSWIN_CHECK_ARG(dh && y && dy && dbias && workspace && M > 0 && N > 0 && N % 8 == 0 && valid_dtype(dtype));
+    PSWIN_CHECK_ARG(dh && y && dy && workspace && M > 0 && N > 0 && N % 8 == 0 && valid_dtype(dtype));
     PSWIN_CHECK_ARG(aligned16(dh) && aligned16(y) && aligned16(dy));
     int blocks = 0;
     int rc = launch<true>(dh, y, dtype, bias, dy, workspace, M, N, (hipStream_t)stream, &blocks);
     if (rc) return rc;
-    launch_colsum(workspace, blocks, N, dbias, (hipStream_t)stream);
+    if (dbias) launch_colsum(workspace, blocks, N, dbias, (hipStream_t)stream);   // else: partial rows only
     PSWIN_LAUNCH_RET();
+}
+
+int pswin_bias_gelu_partial_rows(long long M, int N, int dtype) {
+    if (M <= 0 || N <= 0 || N % 8 || !valid_dtype(dtype)) return PSWIN_ERR_ARG;
+    const int gw = pick_gw(N / (dtype == PSWIN_BF16 ? 8 : 4));
+    const int unr = g_unr_bwd == 1 ? 1 : (g_unr_bwd == 2 ? 2 : 4);
+    const long long bx = row_blocks(M, THREADS / gw, unr);
+    return bx > 0x7fffffffll ? PSWIN_ERR_ARG : (int)bx;
 }
 
 }  // extern "C"

@@ -380,11 +380,11 @@ extern "C" int pswin_colsum_workspace(long long M, int N, int dtype) {
 }
 
 extern "C" int pswin_colsum(const void* x, int dtype, long long M, int N, float* out, float* workspace, void* stream) {
-    PSWIN_CHECK_ARG(x && out && workspace && M > 0 && N > 0 && valid_dtype(dtype));
+    PSWIN_CHECK_ARG(x && workspace && M > 0 && N > 0 && valid_dtype(dtype));
     PSWIN_CHECK_ARG(N % 8 == 0 && aligned16(x));
     const int ve = dtype == PSWIN_BF16 ? 8 : 4;
     const int vpr = N / ve;
-    if (M <= ROWSUM_DIRECT_MAX_ROWS && vpr >= 32 * 64) {       // >= 64 blocks of column groups: one pass is enough
+    if (out && M <= ROWSUM_DIRECT_MAX_ROWS && vpr >= 32 * 64) { // >= 64 blocks of column groups: one pass is enough
         if (dtype == PSWIN_BF16)
             hipLaunchKernelGGL(rowsum_direct_kernel<PSWIN_BF16>, dim3((vpr + 31) / 32), dim3(256), 0,
                                (hipStream_t)stream, x, (int)M, N, vpr, out);
@@ -402,6 +402,144 @@ extern "C" int pswin_colsum(const void* x, int dtype, long long M, int N, float*
     else
         hipLaunchKernelGGL(rowsum_partial_kernel<PSWIN_F32>, dim3(blocks, ychunks), dim3(256), 0, (hipStream_t)stream,
                            x, M, N, vpr, vprb, workspace);
-    launch_colsum(workspace, blocks, N, out, (hipStream_t)stream);
+    if (out) launch_colsum(workspace, blocks, N, out, (hipStream_t)stream);     // else: partial rows only
+    PSWIN_LAUNCH_RET();
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Grouped column sums.  A backward pass ends ~120 small "sum these partial rows" reductions (split-K weight-gradient
+// partials, bias-gradient partial rows, LayerNorm dgamma/dbeta rows); as separate launches each costs 5-8 us of mostly
+// idle GPU.  Their results are only needed once the pass is over, so the host queues them and this kernel runs up to
+// 96 of them in ONE launch: the job table travels in the kernel arguments (no device-side table to keep alive, and a
+// captured hipGraph holds it by value), every 1024-thread block looks its job up with a binary search over the
+// first-block prefix.  Per job the block is shaped G column groups (16 bytes) x RL row lanes, RL in {1, 8, 64} chosen
+// from the row count; a row lane adds its rows in ascending order and the lanes are combined in a fixed order.
+// ------------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int RJ_MAX = 96;
+struct RJob {
+    const void* src;
+    float* dst;
+    int rows, groups, ld, first_block, lane_shift, dtype;
+};
+struct RBatch {
+    RJob job[RJ_MAX];
+    int n;
+};
+static_assert(sizeof(RBatch) <= 4000, "the job table must fit the 4 KB kernel-argument segment");
+
+__global__ __launch_bounds__(1024) void reduce_jobs_kernel(const RBatch b) {
+    __shared__ float red[1024 * 8];
+    int lo = 0, hi = b.n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (b.job[mid].first_block <= (int)blockIdx.x) lo = mid;
+        else hi = mid - 1;
+    }
+    const void* src = b.job[lo].src;
+    float* dst = b.job[lo].dst;
+    const int rows = b.job[lo].rows, groups = b.job[lo].groups, ld = b.job[lo].ld;
+    const int sh = b.job[lo].lane_shift, first = b.job[lo].first_block;
+    const bool bf = b.job[lo].dtype == PSWIN_BF16;
+    const int RL = 1 << sh, G = 1024 >> sh;
+    const int gl = threadIdx.x & (G - 1), rl = threadIdx.x >> (10 - sh);
+    const int grp = ((int)blockIdx.x - first) * G + gl;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    if (grp < groups) {
+        const char* p = reinterpret_cast<const char*>(src) + (size_t)grp * 16;
+        const size_t stride = (size_t)ld * (bf ? 2 : 4);
+        if (bf) {
+#pragma unroll 8
+            for (int r = rl; r < rows; r += RL) {
+                const u32x4 raw = *reinterpret_cast<const u32x4*>(p + (size_t)r * stride);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[2 * e] += __builtin_bit_cast(float, raw[e] << 16);
+                    acc[2 * e + 1] += __builtin_bit_cast(float, raw[e] & 0xffff0000u);
+                }
+            }
+        } else {
+#pragma unroll 8
+            for (int r = rl; r < rows; r += RL) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(p + (size_t)r * stride);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] += v[e];
+            }
+        }
+    }
+    if (sh != 0) {                                     // uniform per block
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = acc[e];
+        __syncthreads();
+        if (sh == 6) {                                 // 64 lanes -> 8: thread (rl < 8, gl) adds lanes rl, rl + 8, ...
+            if (rl < 8) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float s = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) s += red[((rl + 8 * k) * G + gl) * 8 + e];
+                    acc[e] = s;
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = acc[e];   // own slot, read by this thread only
+            }
+            __syncthreads();
+        }
+        if (rl == 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float s = 0.f;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) s += red[(k * G + gl) * 8 + e];
+                acc[e] = s;
+            }
+        }
+    }
+    if (rl == 0 && grp < groups) {
+        if (bf) {
+            f32x4 a = {acc[0], acc[1], acc[2], acc[3]}, c = {acc[4], acc[5], acc[6], acc[7]};
+            *reinterpret_cast<f32x4*>(dst + (size_t)grp * 8) = a;
+            *reinterpret_cast<f32x4*>(dst + (size_t)grp * 8 + 4) = c;
+        } else {
+            f32x4 a = {acc[0], acc[1], acc[2], acc[3]};
+            *reinterpret_cast<f32x4*>(dst + (size_t)grp * 4) = a;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int pswin_reduce_jobs(const pswin_reduce_job* jobs, int n_jobs, void* stream) {
+    PSWIN_CHECK_ARG(jobs && n_jobs > 0);
+    for (int j = 0; j < n_jobs; ++j) {
+        const pswin_reduce_job& q = jobs[j];
+        const int ve = q.dtype == PSWIN_BF16 ? 8 : 4;
+        PSWIN_CHECK_ARG(q.src && q.dst && valid_dtype(q.dtype) && q.rows > 0 && q.cols > 0 && q.cols % ve == 0);
+        PSWIN_CHECK_ARG(q.ld >= q.cols && q.ld % ve == 0 && aligned16(q.src) && aligned16(q.dst));
+    }
+    for (int at = 0; at < n_jobs; at += RJ_MAX) {
+        RBatch b;
+        b.n = n_jobs - at < RJ_MAX ? n_jobs - at : RJ_MAX;
+        long long blocks = 0;
+        for (int j = 0; j < b.n; ++j) {
+            const pswin_reduce_job& q = jobs[at + j];
+            RJob& r = b.job[j];
+            r.src = q.src;
+            r.dst = q.dst;
+            r.rows = q.rows;
+            r.groups = q.cols / (q.dtype == PSWIN_BF16 ? 8 : 4);
+            r.ld = q.ld;
+            r.dtype = q.dtype;
+            r.lane_shift = q.rows <= 16 ? 0 : (q.rows <= 128 ? 3 : 6);
+            r.first_block = (int)blocks;
+            const int G = 1024 >> r.lane_shift;
+            blocks += (r.groups + G - 1) / G;
+        }
+        PSWIN_CHECK_ARG(blocks < 0x7fffffffll);
+        hipLaunchKernelGGL(reduce_jobs_kernel, dim3((unsigned)blocks), dim3(1024), 0, (hipStream_t)stream, b);
+    }
     PSWIN_LAUNCH_RET();
 }

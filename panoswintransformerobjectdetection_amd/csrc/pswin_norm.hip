@@ -517,6 +517,11 @@ extern "C" int pswin_ln_workspace(long long rows, int C) {
     return bwd_blocks(rows, pick_lanes(C)) * 3 * C;
 }
 
+extern "C" int pswin_ln_partial_rows(long long rows, int C) {
+    if (rows <= 0 || C <= 0 || C % 8) return PSWIN_ERR_ARG;
+    return bwd_blocks(rows, pick_lanes(C));
+}
+
 extern "C" int pswin_ln_gather_fwd(const void* x, int x_dtype, const int32_t* map, const float* gamma,
                                    const float* beta, float eps, void* y, int y_dtype, float* mean, float* rstd, int B,
                                    int S, int n_out, int C, void* stream) {
@@ -537,7 +542,8 @@ extern "C" int pswin_ln_gather_bwd(const void* dy, int dy_dtype, const int32_t* 
                                    const float* mean, const float* rstd, const float* gamma, const float* dres,
                                    const float* res_scale, float* dres_sum, void* dx, float* dgamma, float* dbeta,
                                    float* workspace, int B, int S, int n_out, int C, void* stream) {
-    PSWIN_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && workspace && B > 0 && S > 0 && n_out > 0);
+    PSWIN_CHECK_ARG(dy && x && mean && rstd && gamma && dx && workspace && B > 0 && S > 0 && n_out > 0);
+    PSWIN_CHECK_ARG((dgamma && dbeta) || (!dgamma && !dbeta));
     PSWIN_CHECK_ARG(valid_dtype(x_dtype) && valid_dtype(dy_dtype));
     PSWIN_CHECK_ARG(C >= 8 && C % 8 == 0 && C <= MAX_C && aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(gamma));
     PSWIN_CHECK_ARG(inv || n_out == S);
@@ -561,8 +567,10 @@ extern "C" int pswin_ln_gather_bwd(const void* dy, int dy_dtype, const int32_t* 
         });
     }
     if (rc) return rc;
-    // partial rows are [dgamma(C) | dbeta(C) | dres_sum(C)]; the outputs may live in different buffers
-    launch_colsum_seg(workspace, blocks, C, dres_sum ? 3 : 2, dgamma, dbeta, dres_sum, (hipStream_t)stream);
+    // partial rows are [dgamma(C) | dbeta(C) | dres_sum(C)]; the outputs may live in different buffers.
+    // dgamma == dbeta == NULL: the caller sums the partial rows itself (pswin_reduce_jobs); dres_sum then only selects
+    // the 3-segment row layout and is not written.
+    if (dgamma) launch_colsum_seg(workspace, blocks, C, dres_sum ? 3 : 2, dgamma, dbeta, dres_sum, (hipStream_t)stream);
     PSWIN_LAUNCH_RET();
 }
 
@@ -586,7 +594,8 @@ extern "C" int pswin_ln_patch_merge_fwd(const void* x, int x_dtype, const float*
 extern "C" int pswin_ln_patch_merge_bwd(const void* dy, int dy_dtype, const void* x, int x_dtype, const float* mean,
                                         const float* rstd, const float* gamma, void* dx, float* dgamma, float* dbeta,
                                         float* workspace, int B, int H, int W, int C, void* stream) {
-    PSWIN_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && workspace && B > 0 && H > 0 && W > 0);
+    PSWIN_CHECK_ARG(dy && x && mean && rstd && gamma && dx && workspace && B > 0 && H > 0 && W > 0);
+    PSWIN_CHECK_ARG((dgamma && dbeta) || (!dgamma && !dbeta));
     PSWIN_CHECK_ARG(valid_dtype(x_dtype) && valid_dtype(dy_dtype));
     const int C4 = 4 * C;
     PSWIN_CHECK_ARG(C >= 16 && C % 16 == 0 && C4 <= MAX_C && aligned16(x) && aligned16(dy) && aligned16(dx) && aligned16(gamma));
@@ -601,7 +610,7 @@ extern "C" int pswin_ln_patch_merge_bwd(const void* dy, int dy_dtype, const void
                                                                               (hipStream_t)stream);
     });
     if (rc) return rc;
-    launch_colsum_seg(workspace, blocks, C4, 2, dgamma, dbeta, nullptr, (hipStream_t)stream);
+    if (dgamma) launch_colsum_seg(workspace, blocks, C4, 2, dgamma, dbeta, nullptr, (hipStream_t)stream);
     PSWIN_LAUNCH_RET();
 }
 
@@ -636,7 +645,8 @@ extern "C" int pswin_ln_nchw_fwd(const float* x, const float* gamma, const float
 extern "C" int pswin_ln_nchw_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                                  const float* dres, float* dx, float* dgamma, float* dbeta, float* workspace, int B, int S,
                                  int C, void* stream) {
-    PSWIN_CHECK_ARG(dy && x && mean && rstd && gamma && dx && dgamma && dbeta && workspace && B > 0 && pswin_ln_nchw_supported(S, C));
+    PSWIN_CHECK_ARG(dy && x && mean && rstd && gamma && dx && workspace && B > 0 && pswin_ln_nchw_supported(S, C));
+    PSWIN_CHECK_ARG((dgamma && dbeta) || (!dgamma && !dbeta));
     PSWIN_CHECK_ARG(aligned16(dy) && aligned16(x) && aligned16(dx) && aligned16(gamma) && aligned16(dres));
     const int L = pick_lanes(C), rpb = THREADS / L;
     const long long rows = (long long)B * S;
@@ -652,6 +662,6 @@ extern "C" int pswin_ln_nchw_bwd(const float* dy, const float* x, const float* m
         default: return PSWIN_ERR_ARG;
     }
 #undef PSWIN_LN_NCHW_B
-    launch_colsum_seg(workspace, blocks, C, 2, dgamma, dbeta, nullptr, (hipStream_t)stream);
+    if (dgamma) launch_colsum_seg(workspace, blocks, C, 2, dgamma, dbeta, nullptr, (hipStream_t)stream);
     PSWIN_LAUNCH_RET();
 }

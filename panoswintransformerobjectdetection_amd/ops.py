@@ -24,6 +24,66 @@ def clear_caches():
 
 
 # ------------------------------------------------------------------------------------------------
+# parameter-gradient reductions: every "sum these partial rows" of the backward pass goes through sum_rows
+# ------------------------------------------------------------------------------------------------
+class _ReduceQueue:
+    enabled = False
+    task = -1            # autograd graph task the queued jobs belong to
+    jobs = []            # (src tensor, byte offset, dtype code, rows, cols, ld, dst tensor)
+
+
+def set_deferred_reductions(on):
+    """on=True: reductions whose result is a PARAMETER gradient (split-K partials of dW, bias-gradient partial rows,
+    LayerNorm dgamma / dbeta rows) are queued while autograd runs and issued as one grouped launch when the backward pass
+    ends (an autograd engine callback), instead of ~120 launches of 5-8 us each.  The returned gradient tensors are
+    therefore filled only once backward() returns: use it when nothing reads ``param.grad`` earlier, i.e. no
+    post-accumulate hooks and no accumulation into existing ``.grad`` tensors (``zero_grad(set_to_none=True)`` or
+    dp.GradReducer(pack=True), which is what bench.py runs).  Returns the previous setting."""
+    prev, _ReduceQueue.enabled = _ReduceQueue.enabled, bool(on)
+    return prev
+
+
+def _launch_reductions(jobs):
+    import ctypes
+    by_dev = {}
+    for j in jobs:
+        by_dev.setdefault(j[0].device, []).append(j)
+    for lst in by_dev.values():
+        arr = (_lib.ReduceJob * len(lst))()
+        for a, (src, off, dt, rows, cols, ld, dst) in zip(arr, lst):
+            a.src, a.dst, a.dtype, a.rows, a.cols, a.ld = src.data_ptr() + off, dst.data_ptr(), dt, rows, cols, ld
+        call("pswin_reduce_jobs", lst[0][0], ctypes.cast(arr, ctypes.c_void_p), len(lst))
+
+
+def flush_reductions():
+    """Issue the queued reductions now (runs by itself at the end of every backward pass that queued any)."""
+    jobs, _ReduceQueue.jobs, _ReduceQueue.task = _ReduceQueue.jobs, [], -1
+    if jobs:
+        _launch_reductions(jobs)
+
+
+def sum_rows(src, rows, cols, ld=None, col_offset=0):
+    """f32 [cols]: out[c] = sum_{r < rows} src.flatten()[r * ld + col_offset + c] in a fixed order (pswin_reduce_jobs).
+    Inside a backward pass with set_deferred_reductions(True) the launch is postponed to the end of that pass."""
+    ld = cols if ld is None else ld
+    if not src.is_contiguous():
+        raise PswinError("sum_rows expects a contiguous source")
+    out = torch.empty(cols, dtype=torch.float32, device=src.device)
+    job = (src, col_offset * src.element_size(), dtype_code(src), rows, cols, ld, out)
+    task = torch._C._current_graph_task_id() if _ReduceQueue.enabled else -1
+    if task == -1:
+        _launch_reductions([job])
+        return out
+    if _ReduceQueue.task != task:                       # first job of this pass (or leftovers of a pass that raised)
+        _ReduceQueue.jobs, _ReduceQueue.task = [], task
+        torch.autograd.Variable._execution_engine.queue_callback(flush_reductions)
+    _ReduceQueue.jobs.append(job)
+    # the queue keeps `out` alive until the launch; hand autograd a fresh view so that AccumulateGrad can still adopt
+    # the buffer as param.grad (it clones tensors that have other owners)
+    return out.view(cols)
+
+
+# ------------------------------------------------------------------------------------------------
 # static (input independent) tables, cached per feature-map shape and device
 # ------------------------------------------------------------------------------------------------
 def window_maps(pano, H, W, shift, device):
@@ -224,27 +284,30 @@ class _LayerNormGather(torch.autograd.Function):
         x, gamma, mean, rstd, inv, res_scale = ctx.saved_tensors
         B, S, C = x.shape
         dx = torch.empty_like(x)
-        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
         dres_sum = None
         if dres is not None:
             if x.dtype != torch.float32:
                 raise PswinError("the residual passthrough of layer_norm_gather needs an fp32 residual stream")
             dres = dres.float().contiguous()
-        if ctx.want_res_sum:
-            if dres is None:
-                raise PswinError("layer_norm_gather(res_bias=...) needs the passthrough output to be used as the shortcut")
-            dres_sum = torch.empty(C, dtype=torch.float32, device=x.device)
+        if ctx.want_res_sum and dres is None:
+            raise PswinError("layer_norm_gather(res_bias=...) needs the passthrough output to be used as the shortcut")
         if dy is None:                                   # only the shortcut was used downstream
-            if dres_sum is not None:
+            if ctx.want_res_sum:
                 g = dres if res_scale is None else dres * res_scale[:, None, None]
                 dres_sum = colsum(g.reshape(-1, C))
             return dres, torch.zeros_like(gamma), torch.zeros_like(gamma), None, None, None, None, None, dres_sum, None
         dy = dy.contiguous()
-        ws = torch.empty(_lib.load().pswin_ln_workspace(B * S, C), dtype=torch.float32, device=x.device)
+        lib = _lib.load()
+        ws = torch.empty(lib.pswin_ln_workspace(B * S, C), dtype=torch.float32, device=x.device)
+        nseg = 3 if ctx.want_res_sum else 2
+        # partial rows only ([dgamma | dbeta | dres_sum] per block); summed by the grouped reduction
         call("pswin_ln_gather_bwd", x, ptr(dy), dtype_code(dy), ptr(inv), ptr(x), dtype_code(x), ptr(mean), ptr(rstd),
-             ptr(gamma), ptr(dres), ptr(res_scale), ptr(dres_sum), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(ws), B, S,
-             ctx.n_out, C, algo_bytes=B * S * C * (dy.element_size() + (2 if dres is None else 3) * x.element_size()))
-        return dx, dgamma, dbeta, None, None, None, None, None, dres_sum, None
+             ptr(gamma), ptr(dres), ptr(res_scale), ptr(dres) if ctx.want_res_sum else None, ptr(dx), None, None, ptr(ws),
+             B, S, ctx.n_out, C, algo_bytes=B * S * C * (dy.element_size() + (2 if dres is None else 3) * x.element_size()))
+        sums = sum_rows(ws, lib.pswin_ln_partial_rows(B * S, C), nseg * C)
+        if ctx.want_res_sum:
+            dres_sum = sums[2 * C:]
+        return dx, sums[:C], sums[C:2 * C], None, None, None, None, None, dres_sum, None
 
 
 def layer_norm_gather(x, gamma, beta, eps, wmap=None, inv=None, out_dtype=None, passthrough=False, res_bias=None,
@@ -287,11 +350,12 @@ class _LayerNormNCHW(torch.autograd.Function):
         if dres is not None:
             dres = dres.float().contiguous()
         dx = torch.empty_like(x)
-        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
-        ws = torch.empty(_lib.load().pswin_ln_workspace(B * S, C), dtype=torch.float32, device=x.device)
-        call("pswin_ln_nchw_bwd", x, ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(dres), ptr(dx), ptr(dgamma),
-             ptr(dbeta), ptr(ws), B, S, C, algo_bytes=(3 if dres is None else 4) * x.numel() * 4)
-        return dx, dgamma, dbeta, None, None, None, None
+        lib = _lib.load()
+        ws = torch.empty(lib.pswin_ln_workspace(B * S, C), dtype=torch.float32, device=x.device)
+        call("pswin_ln_nchw_bwd", x, ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(dres), ptr(dx), None, None,
+             ptr(ws), B, S, C, algo_bytes=(3 if dres is None else 4) * x.numel() * 4)
+        sums = sum_rows(ws, lib.pswin_ln_partial_rows(B * S, C), 2 * C)
+        return dx, sums[:C], sums[C:], None, None, None, None
 
 
 def layer_norm_nchw(x, gamma, beta, eps, H, W, passthrough=False):
@@ -329,12 +393,13 @@ class _LayerNormPatchMerge(torch.autograd.Function):
         H, W = ctx.geom
         dy = dy.contiguous()
         dx = torch.empty_like(x)
-        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
         rows = B * ((H + 1) // 2) * ((W + 1) // 2)
-        ws = torch.empty(_lib.load().pswin_ln_workspace(rows, 4 * C), dtype=torch.float32, device=x.device)
+        lib = _lib.load()
+        ws = torch.empty(lib.pswin_ln_workspace(rows, 4 * C), dtype=torch.float32, device=x.device)
         call("pswin_ln_patch_merge_bwd", x, ptr(dy), dtype_code(dy), ptr(x), dtype_code(x), ptr(mean), ptr(rstd),
-             ptr(gamma), ptr(dx), ptr(dgamma), ptr(dbeta), ptr(ws), B, H, W, C)
-        return dx, dgamma, dbeta, None, None, None, None
+             ptr(gamma), ptr(dx), None, None, ptr(ws), B, H, W, C)
+        sums = sum_rows(ws, lib.pswin_ln_partial_rows(rows, 4 * C), 8 * C)
+        return dx, sums[:4 * C], sums[4 * C:], None, None, None, None
 
 
 def layer_norm_patch_merge(x, gamma, beta, eps, H, W, out_dtype=None):
@@ -396,10 +461,12 @@ def colsum(x2d):
     """fp32 column sums of a [M, N] matrix (N % 8 == 0): bias gradients and split-K partial reductions."""
     x2d = x2d.contiguous()
     M, N = x2d.shape
-    out = torch.empty(N, dtype=torch.float32, device=x2d.device)
-    ws = torch.empty(_lib.load().pswin_colsum_workspace(M, N, dtype_code(x2d)), dtype=torch.float32, device=x2d.device)
-    call("pswin_colsum", x2d, ptr(x2d), dtype_code(x2d), M, N, ptr(out), ptr(ws))
-    return out
+    if M <= 4096:
+        return sum_rows(x2d, M, N)
+    n_ws = _lib.load().pswin_colsum_workspace(M, N, dtype_code(x2d))
+    ws = torch.empty(n_ws, dtype=torch.float32, device=x2d.device)
+    call("pswin_colsum", x2d, ptr(x2d), dtype_code(x2d), M, N, None, ptr(ws))      # first stage: partial rows
+    return sum_rows(ws, n_ws // N, N)
 
 
 def skinny_gemm_supported(x2d, n_out):
@@ -446,16 +513,17 @@ class _Fc1Gelu(torch.autograd.Function):
         N = wb.shape[0]
         dh = dh.to(x.dtype).contiguous()
         dy = torch.empty_like(dh)
-        db = torch.empty(N, dtype=torch.float32, device=x.device)
-        ws = torch.empty(_lib.load().pswin_fc1_gelu_workspace(N), dtype=torch.float32, device=x.device)
-        call("pswin_fc1_gelu_bwd", x, ptr(x), ptr(wb), ptr(b), ptr(dh), ptr(dy), ptr(db), ptr(ws), M, K, N,
+        lib = _lib.load()
+        ws = torch.empty(lib.pswin_fc1_gelu_workspace(N), dtype=torch.float32, device=x.device)
+        call("pswin_fc1_gelu_bwd", x, ptr(x), ptr(wb), ptr(b), ptr(dh), ptr(dy), None, ptr(ws), M, K, N,
              algo_bytes=2 * M * (K + 2 * N))
+        db = sum_rows(ws, lib.pswin_fc1_gelu_partial_rows(M), N)
         dx = skinny_gemm(dy, wb, None, transpose_w=True) if ctx.needs_input_grad[0] else None
         from .backbone import _pick_split
         ch = _pick_split(M, -(-N // 64) * -(-K // 64))
         if ch > 1:
             part = torch.bmm(dy.view(ch, M // ch, N).transpose(1, 2), x.view(ch, M // ch, K))
-            dw = colsum(part.view(ch, N * K)).view(N, K)
+            dw = sum_rows(part, ch, N * K).view(N, K)
         else:
             dw = (dy.t() @ x).float()
         return dx, dw, db, None
@@ -487,11 +555,12 @@ class _BiasGelu(torch.autograd.Function):
         M, N = y.numel() // y.shape[-1], y.shape[-1]
         dh = dh.to(y.dtype).contiguous()
         dy = torch.empty_like(y)
-        db = torch.empty(N, dtype=torch.float32, device=y.device)
-        ws = torch.empty(_lib.load().pswin_bias_gelu_workspace(M, N), dtype=torch.float32, device=y.device)
-        call("pswin_bias_gelu_bwd", y, ptr(dh), ptr(y), dtype_code(y), ptr(b), ptr(dy), ptr(db), ptr(ws), M, N,
+        lib = _lib.load()
+        ws = torch.empty(lib.pswin_bias_gelu_workspace(M, N), dtype=torch.float32, device=y.device)
+        call("pswin_bias_gelu_bwd", y, ptr(dh), ptr(y), dtype_code(y), ptr(b), ptr(dy), None, ptr(ws), M, N,
              algo_bytes=3 * y.numel() * y.element_size())
-        return dy, (db if b is not None else None)
+        db = sum_rows(ws, lib.pswin_bias_gelu_partial_rows(M, N, dtype_code(y)), N) if b is not None else None
+        return dy, db
 
 
 def bias_gelu(y, bias):

@@ -343,6 +343,30 @@ def test_colsum(ops, M, N, dt):
     assert torch.allclose(got, ref, rtol=1e-4, atol=1e-3)
 
 
+def test_grouped_reduction_many_jobs(ops):
+    """pswin_reduce_jobs: 230 independent column sums (3 launches of <= 96 jobs) with every block shape (1 / 8 / 64 row
+    lanes), both source dtypes, row strides larger than the summed width and a column offset, against float64 sums."""
+    import random
+    rnd = random.Random(7)
+    jobs, want = [], []
+    for i in range(230):
+        dt = torch.bfloat16 if i % 3 else torch.float32
+        ve = 8 if dt == torch.bfloat16 else 4
+        rows = rnd.choice([1, 2, 7, 16, 17, 60, 128, 129, 700, 1536])
+        cols = ve * rnd.choice([1, 3, 12, 48, 130, 1153])
+        pad = ve * rnd.choice([0, 0, 2])
+        off = ve * rnd.choice([0, 1]) if pad else 0
+        ld = cols + pad
+        src = (det_uniform((rows, ld), f"rj{i}") * 2).to(dt).to(DEV)
+        jobs.append((src, off * src.element_size(), 1 if dt == torch.bfloat16 else 0, rows, cols, ld,
+                     torch.full((cols,), float("nan"), device=DEV)))
+        want.append(src.double()[:, off:off + cols].sum(0))
+    ops._launch_reductions(jobs)
+    torch.cuda.synchronize()
+    for j, w in zip(jobs, want):
+        assert torch.allclose(j[6].double(), w, rtol=1e-5, atol=1e-4), (j[3], j[4], j[5])
+
+
 def test_rejects_cpu_and_bad_args(ops):
     from panoswintransformerobjectdetection_amd import PswinError
     with pytest.raises(PswinError):
