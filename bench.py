@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); 'gloo' lets two "
                     "ranks rehearse the N > 1 code path on one GPU together with --device")
     ap.add_argument("--device", type=int, default=None, help="force this HIP device index for every rank (rehearsal only)")
+    ap.add_argument("--no-defer", action="store_true",
+                    help="issue every parameter-gradient reduction where autograd produces it (A/B of the grouped launch)")
     ap.add_argument("--split-backward", action="store_true",
                     help="use the two-graph step (backward in two pieces, all-reduce overlapped) also on one GPU")
     ap.add_argument("--kernel-steps", type=int, default=3,
@@ -111,7 +113,7 @@ def main():
     # pack mode reads param.grad only after backward() has returned: the parameter-gradient reductions of the pass can
     # then be issued as one grouped launch at its end (ops.set_deferred_reductions)
     from panoswintransformerobjectdetection_amd import ops as _ops
-    _ops.set_deferred_reductions(not args.eager)
+    _ops.set_deferred_reductions(not args.eager and not args.no_defer)
     reducer.broadcast_parameters(model)
     # one parameter group (as the reference's AdamW config): the optimizer runs over ONE flat parameter / gradient /
     # state buffer (dp.GradReducer.flatten_parameters), i.e. a single fused element-wise launch per step

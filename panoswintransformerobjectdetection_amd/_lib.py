@@ -68,6 +68,7 @@ _PROTOTYPES = {
     "pswin_colsum_workspace": [ctypes.c_longlong, _i, _i],
     "pswin_colsum": [_vp, _i, ctypes.c_longlong, _i, _vp, _vp, _vp],
     "pswin_reduce_jobs": [_vp, _i, _vp],
+    "pswin_attn_table_grads_batch": [_vp, _i, _i, _vp],
     "pswin_ln_partial_rows": [ctypes.c_longlong, _i],
     "pswin_bias_gelu_partial_rows": [ctypes.c_longlong, _i, _i],
     "pswin_fc1_gelu_partial_rows": [ctypes.c_longlong],
@@ -93,6 +94,13 @@ class ReduceJob(ctypes.Structure):
     """pswin_reduce_job of include/pswin.h"""
     _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("dtype", ctypes.c_int), ("rows", ctypes.c_int),
                 ("cols", ctypes.c_int), ("ld", ctypes.c_int)]
+
+
+class TableGradJob(ctypes.Structure):
+    """pswin_table_grad_job of include/pswin.h"""
+    _fields_ = [("dscore_sum", ctypes.c_void_p), ("dist_tiles_t", ctypes.c_void_p), ("dalpha", ctypes.c_void_p),
+                ("dbeta", ctypes.c_void_p), ("workspace", ctypes.c_void_p), ("n_tiles", ctypes.c_int),
+                ("n_bias_windows", ctypes.c_int), ("n_dist", ctypes.c_int), ("heads", ctypes.c_int)]
 
 
 def exported_symbols():

@@ -990,17 +990,40 @@ constexpr int DTAB_BLOCKS = 128;
 constexpr int DTAB_THREADS = 256;
 constexpr int DTAB_EPT = (TOK * TOK + DTAB_THREADS - 1) / DTAB_THREADS;   // 10 (i, j) pairs per thread
 
-// Stage 1: per block and head, sum over a strided subset of the G tiles of g and g * d for every (i, j) pair.  A
+// Table-gradient jobs of one backward pass (one per attention module) run as TWO launches for all of them; the job table
+// travels in the kernel arguments.
+constexpr int TJ_MAX = 32;
+struct TJob {
+    const float* g;        // dScore sums [n_tiles][heads][64 j][64 i]
+    const float* dist_t;   // [n_dist][64 j][64 i] or NULL
+    float* partial;        // [blocks][heads][2][49*49]
+    float* dalpha;         // [169][heads] or NULL
+    float* dbeta;          // [169][heads]
+    int n_tiles, nb, n_dist, heads, blocks;
+    int first1, first2;    // first workgroup of this job in the stage-1 / stage-2 grid
+};
+struct TBatch {
+    TJob job[TJ_MAX];
+    int n;
+};
+static_assert(sizeof(TBatch) <= 4000, "the job table must fit the kernel-argument segment");
+
+// Stage 1: per (block, head) of a job, sum over a strided subset of the tiles of g and g * d for every (i, j) pair.  A
 // thread owns the same 10 pairs for every tile, so the sums stay in registers (no atomics).
-// g tiles: [n_tiles][heads][64 j][64 i]; dist_t tiles: [n_dist][64 j][64 i]; partial: [block][heads][2][49*49]
-__global__ __launch_bounds__(DTAB_THREADS) void dtab_partial_kernel(const float* __restrict__ g, int n_tiles, int nb,
-                                                                    const float* __restrict__ dist_t, int n_dist,
-                                                                    int heads, float* __restrict__ partial) {
-    const int h = blockIdx.y;
+__global__ __launch_bounds__(DTAB_THREADS) void dtab_partial_kernel(const TBatch b) {
+    int jn = 0;
+    for (int q = 1; q < b.n; ++q)
+        if (b.job[q].first1 <= (int)blockIdx.x) jn = q;
+    const float* __restrict__ g = b.job[jn].g;
+    const float* __restrict__ dist_t = b.job[jn].dist_t;
+    const int heads = b.job[jn].heads, n_tiles = b.job[jn].n_tiles, nb = b.job[jn].nb, n_dist = b.job[jn].n_dist;
+    const int nblk = b.job[jn].blocks;
+    const int local = (int)blockIdx.x - b.job[jn].first1;
+    const int blk = local / heads, h = local - blk * heads;
     float sb[DTAB_EPT], sa[DTAB_EPT];
 #pragma unroll
     for (int k = 0; k < DTAB_EPT; ++k) sb[k] = sa[k] = 0.f;
-    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    for (int tile = blk; tile < n_tiles; tile += nblk) {
         const float* gt = g + ((size_t)tile * heads + h) * (PADT * PADT);
         const float* dt = dist_t ? dist_t + (size_t)((tile % nb) % n_dist) * (PADT * PADT) : nullptr;
 #pragma unroll
@@ -1014,7 +1037,7 @@ __global__ __launch_bounds__(DTAB_THREADS) void dtab_partial_kernel(const float*
             }
         }
     }
-    float* out = partial + ((size_t)blockIdx.x * heads + h) * 2 * TOK * TOK;
+    float* out = b.job[jn].partial + ((size_t)blk * heads + h) * 2 * TOK * TOK;
 #pragma unroll
     for (int k = 0; k < DTAB_EPT; ++k) {
         const int e = threadIdx.x + k * DTAB_THREADS;
@@ -1025,25 +1048,38 @@ __global__ __launch_bounds__(DTAB_THREADS) void dtab_partial_kernel(const float*
     }
 }
 
-// Stage 2 (after the fixed-order column sum over blocks): one WAVE per (table entry, head): lane l < 49 is the key
-// position (hj, wj) = (l / 7, l % 7) and loads the one pair (i, j) with hi - hj = dh, wi - wj = dw if it exists; a
-// butterfly reduction (fixed order) finishes the bin.  (One thread per bin walking its <= 49 pairs was a chain of
-// dependent loads: 17 us for 507 outputs.)   summed: [heads][2][49*49]
-__global__ __launch_bounds__(256) void dtab_final_kernel(const float* __restrict__ summed, int heads, bool has_dist,
-                                                         float* __restrict__ dalpha, float* __restrict__ dbeta) {
-    const int t = blockIdx.x * 4 + (threadIdx.x >> 6);     // over 169 * heads, wave-uniform
+// Stage 2: one WAVE per (table entry, head) of a job: lane l < 49 is the key position (hj, wj) = (l / 7, l % 7) and
+// owns the one pair (i, j) with hi - hj = dh, wi - wj = dw if it exists; it adds that pair over the job's stage-1
+// blocks in ascending order (independent loads), then a butterfly reduction (fixed order) finishes the bin.
+__global__ __launch_bounds__(256) void dtab_final_kernel(const TBatch b) {
+    int jn = 0;
+    for (int q = 1; q < b.n; ++q)
+        if (b.job[q].first2 <= (int)blockIdx.x) jn = q;
+    const int heads = b.job[jn].heads, nblk = b.job[jn].blocks;
+    const bool has_dist = b.job[jn].dist_t != nullptr;
+    const float* __restrict__ partial = b.job[jn].partial;
+    const int t = ((int)blockIdx.x - b.job[jn].first2) * 4 + (threadIdx.x >> 6);     // over 169 * heads, wave-uniform
     const int lane = threadIdx.x & 63;
     if (t >= NBINS * heads) return;
     const int idx = t / heads, h = t - idx * heads;
     const int dh = idx / (2 * PSWIN_WS - 1) - (PSWIN_WS - 1), dw = idx % (2 * PSWIN_WS - 1) - (PSWIN_WS - 1);
-    const float* p = summed + (size_t)h * 2 * TOK * TOK;
     const int hj = lane / PSWIN_WS, wj = lane - hj * PSWIN_WS;
     const int hi = hj + dh, wi = wj + dw;
     float sb = 0.f, sa = 0.f;
     if (lane < TOK && hi >= 0 && hi < PSWIN_WS && wi >= 0 && wi < PSWIN_WS) {
         const int e = lane * TOK + hi * PSWIN_WS + wi;     // j * 49 + i
-        sb = p[e];
-        if (has_dist) sa = p[TOK * TOK + e];
+        const size_t stride = (size_t)heads * 2 * TOK * TOK;
+        const float* p = partial + (size_t)h * 2 * TOK * TOK + e;
+        if (has_dist) {
+#pragma unroll 4
+            for (int q = 0; q < nblk; ++q) {
+                sb += p[q * stride];
+                sa += p[q * stride + TOK * TOK];
+            }
+        } else {
+#pragma unroll 8
+            for (int q = 0; q < nblk; ++q) sb += p[q * stride];
+        }
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
@@ -1051,8 +1087,8 @@ __global__ __launch_bounds__(256) void dtab_final_kernel(const float* __restrict
         sa += __shfl_xor(sa, m, 64);
     }
     if (lane == 0) {
-        dbeta[t] = sb;
-        if (dalpha) dalpha[t] = sa;
+        b.job[jn].dbeta[t] = sb;
+        if (has_dist) b.job[jn].dalpha[t] = sa;
     }
 }
 
@@ -1169,21 +1205,42 @@ extern "C" int pswin_attn_bwd(const void* q, const void* k, const void* v, int l
     PSWIN_LAUNCH_RET();
 }
 
+extern "C" int pswin_attn_table_grads_batch(const pswin_table_grad_job* jobs, int n_jobs, int stages, void* stream) {
+    PSWIN_CHECK_ARG(jobs && n_jobs > 0 && stages >= 1 && stages <= 3);
+    for (int j = 0; j < n_jobs; ++j) {
+        const pswin_table_grad_job& q = jobs[j];
+        PSWIN_CHECK_ARG(q.dscore_sum && q.dbeta && q.workspace && q.n_tiles > 0 && q.n_bias_windows > 0 && q.heads > 0);
+        PSWIN_CHECK_ARG(q.n_tiles % q.n_bias_windows == 0);
+        PSWIN_CHECK_ARG(!q.dist_tiles_t || (q.dalpha && q.n_dist > 0 && q.n_bias_windows % q.n_dist == 0));
+    }
+    for (int at = 0; at < n_jobs; at += TJ_MAX) {
+        TBatch b;
+        b.n = n_jobs - at < TJ_MAX ? n_jobs - at : TJ_MAX;
+        long long g1 = 0, g2 = 0;
+        for (int j = 0; j < b.n; ++j) {
+            const pswin_table_grad_job& q = jobs[at + j];
+            TJob& t = b.job[j];
+            // tiles are ordered (chunk, wb, h): tile x of head h belongs to bias window x % n_bias_windows
+            t.g = q.dscore_sum; t.dist_t = q.dist_tiles_t; t.partial = q.workspace;
+            t.dalpha = q.dist_tiles_t ? q.dalpha : nullptr; t.dbeta = q.dbeta;
+            t.n_tiles = q.n_tiles; t.nb = q.n_bias_windows; t.n_dist = q.dist_tiles_t ? q.n_dist : 1; t.heads = q.heads;
+            t.blocks = q.n_tiles < DTAB_BLOCKS ? q.n_tiles : DTAB_BLOCKS;
+            t.first1 = (int)g1; t.first2 = (int)g2;
+            g1 += (long long)t.blocks * q.heads;
+            g2 += (NBINS * q.heads + 3) / 4;
+        }
+        PSWIN_CHECK_ARG(g1 < 0x7fffffffll && g2 < 0x7fffffffll);
+        if (stages & 1)
+            hipLaunchKernelGGL(dtab_partial_kernel, dim3((unsigned)g1), dim3(DTAB_THREADS), 0, (hipStream_t)stream, b);
+        if (stages & 2)
+            hipLaunchKernelGGL(dtab_final_kernel, dim3((unsigned)g2), dim3(256), 0, (hipStream_t)stream, b);
+    }
+    PSWIN_LAUNCH_RET();
+}
+
 extern "C" int pswin_attn_table_grads(const float* dscore_sum, int n_tiles, int n_bias_windows, const float* dist_t,
                                       int n_dist, int heads, float* dalpha, float* dbeta, float* workspace,
                                       void* stream) {
-    PSWIN_CHECK_ARG(dscore_sum && dbeta && workspace && n_tiles > 0 && n_bias_windows > 0 && heads > 0);
-    PSWIN_CHECK_ARG(n_tiles % n_bias_windows == 0);
-    PSWIN_CHECK_ARG(!dist_t || (dalpha && n_dist > 0 && n_bias_windows % n_dist == 0));
-    // tiles are ordered (chunk, wb, h): tile x of head h belongs to bias window x % n_bias_windows
-    const int blocks = n_tiles < DTAB_BLOCKS ? n_tiles : DTAB_BLOCKS;
-    const int ncol = heads * 2 * TOK * TOK;
-    float* partial = workspace;
-    float* summed = partial + (size_t)DTAB_BLOCKS * ncol;
-    hipLaunchKernelGGL(dtab_partial_kernel, dim3(blocks, heads), dim3(DTAB_THREADS), 0, (hipStream_t)stream, dscore_sum,
-                       n_tiles, n_bias_windows, dist_t, dist_t ? n_dist : 1, heads, partial);
-    launch_colsum(partial, blocks, ncol, summed, (hipStream_t)stream);
-    hipLaunchKernelGGL(dtab_final_kernel, dim3((NBINS * heads + 3) / 4), dim3(256), 0, (hipStream_t)stream, summed,
-                       heads, dist_t != nullptr, dist_t ? dalpha : nullptr, dbeta);
-    PSWIN_LAUNCH_RET();
+    pswin_table_grad_job q = {dscore_sum, dist_t, dalpha, dbeta, workspace, n_tiles, n_bias_windows, n_dist, heads};
+    return pswin_attn_table_grads_batch(&q, 1, 3, stream);
 }

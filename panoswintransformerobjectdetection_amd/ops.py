@@ -55,11 +55,36 @@ def _launch_reductions(jobs):
         call("pswin_reduce_jobs", lst[0][0], ctypes.cast(arr, ctypes.c_void_p), len(lst))
 
 
+def _launch_table_grads(jobs, stages=3):
+    import ctypes
+    by_dev = {}
+    for j in jobs:
+        by_dev.setdefault(j[0].device, []).append(j)
+    for lst in by_dev.values():
+        arr = (_lib.TableGradJob * len(lst))()
+        for a, (gsum, dist_t, dalpha, dbeta, ws, n_tiles, nb, n_dist, heads) in zip(arr, lst):
+            a.dscore_sum, a.dist_tiles_t = gsum.data_ptr(), (None if dist_t is None else dist_t.data_ptr())
+            a.dalpha, a.dbeta, a.workspace = (None if dalpha is None else dalpha.data_ptr()), dbeta.data_ptr(), ws.data_ptr()
+            a.n_tiles, a.n_bias_windows, a.n_dist, a.heads = n_tiles, nb, n_dist, heads
+        call("pswin_attn_table_grads_batch", lst[0][0], ctypes.cast(arr, ctypes.c_void_p), len(lst), stages)
+
+
 def flush_reductions():
     """Issue the queued reductions now (runs by itself at the end of every backward pass that queued any)."""
     jobs, _ReduceQueue.jobs, _ReduceQueue.task = _ReduceQueue.jobs, [], -1
     if jobs:
         _launch_reductions(jobs)
+
+
+def _deferring():
+    """True inside a backward pass with deferred reductions on; arms the end-of-pass callback on first use."""
+    task = torch._C._current_graph_task_id() if _ReduceQueue.enabled else -1
+    if task == -1:
+        return False
+    if _ReduceQueue.task != task:                       # first job of this pass (or leftovers of a pass that raised)
+        _ReduceQueue.jobs, _ReduceQueue.task = [], task
+        torch.autograd.Variable._execution_engine.queue_callback(flush_reductions)
+    return True
 
 
 def sum_rows(src, rows, cols, ld=None, col_offset=0):
@@ -70,13 +95,9 @@ def sum_rows(src, rows, cols, ld=None, col_offset=0):
         raise PswinError("sum_rows expects a contiguous source")
     out = torch.empty(cols, dtype=torch.float32, device=src.device)
     job = (src, col_offset * src.element_size(), dtype_code(src), rows, cols, ld, out)
-    task = torch._C._current_graph_task_id() if _ReduceQueue.enabled else -1
-    if task == -1:
+    if not _deferring():
         _launch_reductions([job])
         return out
-    if _ReduceQueue.task != task:                       # first job of this pass (or leftovers of a pass that raised)
-        _ReduceQueue.jobs, _ReduceQueue.task = [], task
-        torch.autograd.Variable._execution_engine.queue_callback(flush_reductions)
     _ReduceQueue.jobs.append(job)
     # the queue keeps `out` alive until the launch; hand autograd a fresh view so that AccumulateGrad can still adopt
     # the buffer as param.grad (it clones tensors that have other owners)
@@ -711,8 +732,11 @@ class _WindowAttention(torch.autograd.Function):
             dbeta = torch.empty(169, heads, dtype=torch.float32, device=x.device)
             dalpha = torch.empty_like(dbeta) if dist is not None else None
             ws = torch.empty(lib.pswin_attn_table_grads_workspace(heads), dtype=torch.float32, device=x.device)
-            call("pswin_attn_table_grads", x, ptr(gsum), chunks * nb, nb, ptr(None if dist is None else dist.bwd),
-                 0 if dist is None else dist.n, heads, ptr(dalpha), ptr(dbeta), ptr(ws))
+            job = (gsum, None if dist is None else dist.bwd, dalpha, dbeta, ws, chunks * nb, nb,
+                   0 if dist is None else dist.n, heads)
+            # Not deferred to the end of the pass (unlike sum_rows): the dScore tiles and the block partials (together
+            # ~0.4 GB per step) are read while still in the last-level cache; postponing either stage measured slower.
+            _launch_table_grads([job])
         return dx, dk, dv, dalpha, dbeta, None, None, None, None, None, None
 
 

@@ -367,6 +367,46 @@ def test_grouped_reduction_many_jobs(ops):
         assert torch.allclose(j[6].double(), w, rtol=1e-5, atol=1e-4), (j[3], j[4], j[5])
 
 
+def test_table_grads_batch_matches_single_jobs(ops):
+    """pswin_attn_table_grads_batch over three modules with different head counts / tile counts (with and without the
+    great-circle table) == the same jobs issued one by one, and == a float64 evaluation of the definition."""
+    from panoswintransformerobjectdetection_amd import _lib
+    lib = _lib.load()
+    idx = torch.tensor([[(i // 7 - j // 7 + 6) * 13 + (i % 7 - j % 7 + 6) for i in range(49)] for j in range(49)])  # [j][i]
+    jobs, want = [], []
+    for n_tiles, nb, n_dist, heads in [(150, 15, 15, 3), (40, 20, 5, 6), (9, 9, 0, 12)]:
+        g = torch.zeros(n_tiles, heads, 64, 64)
+        g[:, :, :49, :49] = det_uniform((n_tiles, heads, 49, 49), f"tg{heads}")
+        dist = None
+        if n_dist:
+            dist = torch.zeros(n_dist, 64, 64)
+            dist[:, :49, :49] = det_uniform((n_dist, 49, 49), f"td{heads}") + 1.0
+        dbeta = torch.full((169, heads), float("nan"), device=DEV)
+        dalpha = torch.full((169, heads), float("nan"), device=DEV) if n_dist else None
+        ws = torch.empty(lib.pswin_attn_table_grads_workspace(heads), device=DEV)
+        jobs.append((g.to(DEV), None if dist is None else dist.to(DEV), dalpha, dbeta, ws, n_tiles, nb, n_dist, heads))
+        gs = g[:, :, :49, :49].double()
+        wb = torch.zeros(169, heads, dtype=torch.float64)
+        wb.index_add_(0, idx.flatten(), gs.sum(0).permute(1, 2, 0).reshape(49 * 49, heads))
+        wa = None
+        if n_dist:
+            d = dist[:, :49, :49].double()[(torch.arange(n_tiles) % nb) % n_dist]            # [tile][j][i]
+            wa = torch.zeros(169, heads, dtype=torch.float64)
+            wa.index_add_(0, idx.flatten(), (gs * d[:, None]).sum(0).permute(1, 2, 0).reshape(49 * 49, heads))
+        want.append((wa, wb))
+    ops._launch_table_grads(jobs)
+    torch.cuda.synchronize()
+    batch = [(None if j[2] is None else j[2].clone(), j[3].clone()) for j in jobs]
+    for j, (ba, bb), (wa, wb) in zip(jobs, batch, want):
+        assert torch.allclose(bb.double().cpu(), wb, rtol=1e-5, atol=1e-4)
+        if wa is not None:
+            assert torch.allclose(ba.double().cpu(), wa, rtol=1e-5, atol=1e-4)
+        j[3].fill_(float("nan"))
+        ops._launch_table_grads([j])
+        torch.cuda.synchronize()
+        assert torch.equal(j[3], bb) and (ba is None or torch.equal(j[2], ba))
+
+
 def test_rejects_cpu_and_bad_args(ops):
     from panoswintransformerobjectdetection_amd import PswinError
     with pytest.raises(PswinError):
