@@ -133,6 +133,7 @@ class _LinearSplitK(torch.autograd.Function):
         wb = w_lp if w_lp is not None else weight.to(x.dtype)
         ctx.save_for_backward(x, wb)
         ctx.has_bias = bias is not None
+        ctx.weight = weight                                 # for ops.grad_slot: dW may be summed straight into its flat slot
         if ops.skinny_gemm_supported(x, wb.shape[0]):       # stage-0 shapes: streaming HIP GEMM, weight resident in LDS
             return ops.skinny_gemm(x, wb, bias)
         bb = None if bias is None else (b_lp if b_lp is not None else bias.to(x.dtype))
@@ -155,7 +156,7 @@ class _LinearSplitK(torch.autograd.Function):
         ch = _pick_split(M, -(-N // 64) * -(-K // 64))
         if ch > 1:
             part = torch.bmm(dy.view(ch, M // ch, N).transpose(1, 2), x.view(ch, M // ch, K))
-            dw = ops.sum_rows(part, ch, N * K).view(N, K)
+            dw = ops.sum_rows(part, ch, N * K, out=ops.grad_slot(ctx.weight)).view(N, K)
         else:
             dw = (dy.t() @ x).float()
         db = ops.colsum(dy) if ctx.has_bias else None

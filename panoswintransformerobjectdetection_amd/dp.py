@@ -63,6 +63,10 @@ class GradReducer:
         for i, p in enumerate(order):
             self._views.append(self.flat[offsets[i]:offsets[i] + p.numel()].view_as(p))
             p.grad = None if pack else self._views[-1]
+            if pack:
+                # backward kernels that produce a whole parameter gradient in one piece may write it here directly
+                # (ops.grad_slot); pack_grads then has nothing to copy for that parameter
+                p._grad_slot = self.flat[offsets[i]:offsets[i] + p.numel()]
             self._bucket_of[p] = len(self.buckets)
             count += 1
             end = offsets[i + 1] if i + 1 < len(order) else total
@@ -93,7 +97,7 @@ class GradReducer:
         if params is not None:
             ids = {id(p) for p in params}
             pairs = [(v, p) for v, p in pairs if id(p) in ids]
-        have = [(v, p.grad) for v, p in pairs if p.grad is not None]
+        have = [(v, p.grad) for v, p in pairs if p.grad is not None and p.grad.data_ptr() != v.data_ptr()]
         for v, p in pairs:
             if p.grad is None:
                 v.zero_()                                         # parameter unused this step: contributes zeros

@@ -30,6 +30,7 @@ class _ReduceQueue:
     enabled = False
     task = -1            # autograd graph task the queued jobs belong to
     jobs = []            # (src tensor, byte offset, dtype code, rows, cols, ld, dst tensor)
+    slot_task, slots = -2, set()    # flat-gradient slots already handed out in the current backward pass (grad_slot)
 
 
 def set_deferred_reductions(on):
@@ -87,12 +88,39 @@ def _deferring():
     return True
 
 
-def sum_rows(src, rows, cols, ld=None, col_offset=0):
+def grad_slot(param):
+    """The flat-gradient-buffer view dp.GradReducer(pack=True) reserved for `param` (``param._grad_slot``) if this backward
+    pass may write the parameter's gradient straight into it: the parameter holds no gradient yet (nothing to accumulate
+    into) and the slot has not been handed out earlier in the same pass (a weight used twice gets a private buffer the
+    second time and autograd adds the two).  None otherwise."""
+    slot = getattr(param, "_grad_slot", None)
+    if slot is None or param.grad is not None or slot.device != param.device:
+        return None
+    task = torch._C._current_graph_task_id()
+    if _ReduceQueue.slot_task != task:
+        _ReduceQueue.slot_task, _ReduceQueue.slots = task, set()
+    if slot.data_ptr() in _ReduceQueue.slots:
+        return None
+    _ReduceQueue.slots.add(slot.data_ptr())
+    return slot
+
+
+def sum_rows(src, rows, cols, ld=None, col_offset=0, out=None):
     """f32 [cols]: out[c] = sum_{r < rows} src.flatten()[r * ld + col_offset + c] in a fixed order (pswin_reduce_jobs).
-    Inside a backward pass with set_deferred_reductions(True) the launch is postponed to the end of that pass."""
+    Inside a backward pass with set_deferred_reductions(True) the launch is postponed to the end of that pass.
+    out: an existing contiguous f32 buffer of `cols` elements to write (see grad_slot); a fresh view of it is returned."""
     ld = cols if ld is None else ld
     if not src.is_contiguous():
         raise PswinError("sum_rows expects a contiguous source")
+    if out is not None:
+        if out.dtype != torch.float32 or out.numel() != cols or not out.is_contiguous():
+            raise PswinError("sum_rows: `out` must be a contiguous float32 buffer of `cols` elements")
+        job = (src, col_offset * src.element_size(), dtype_code(src), rows, cols, ld, out)
+        if _deferring():
+            _ReduceQueue.jobs.append(job)
+        else:
+            _launch_reductions([job])
+        return out.view(cols)
     out = torch.empty(cols, dtype=torch.float32, device=src.device)
     job = (src, col_offset * src.element_size(), dtype_code(src), rows, cols, ld, out)
     if not _deferring():
@@ -525,6 +553,7 @@ class _Fc1Gelu(torch.autograd.Function):
         b = bias.detach().float().contiguous()
         call("pswin_fc1_gelu_fwd", x, ptr(x), ptr(wb), ptr(b), ptr(h), M, K, N, algo_bytes=2 * M * (K + N))
         ctx.save_for_backward(x, wb, b)
+        ctx.weight = weight
         return h
 
     @staticmethod
@@ -544,7 +573,7 @@ class _Fc1Gelu(torch.autograd.Function):
         ch = _pick_split(M, -(-N // 64) * -(-K // 64))
         if ch > 1:
             part = torch.bmm(dy.view(ch, M // ch, N).transpose(1, 2), x.view(ch, M // ch, K))
-            dw = sum_rows(part, ch, N * K).view(N, K)
+            dw = sum_rows(part, ch, N * K, out=grad_slot(ctx.weight)).view(N, K)
         else:
             dw = (dy.t() @ x).float()
         return dx, dw, db, None

@@ -122,6 +122,44 @@ def test_hipgraph_replay_matches_eager():
     del eager_deferred
 
 
+def test_weight_gradients_land_in_the_flat_gradient_buffer():
+    """dp.GradReducer(pack=True) + deferred reductions: the split-K weight gradients of the Linear layers are summed
+    straight into their slots of the flat gradient buffer (ops.grad_slot), pack_grads copies only the rest, and the
+    buffer holds exactly the gradients of a plain backward pass."""
+    from panoswintransformerobjectdetection_amd import SimplePanoSwinTransformer, ops
+    from panoswintransformerobjectdetection_amd.dp import GradReducer
+    cfg = dict(embed_dim=96, depths=[2, 2, 2, 2], num_heads=[3, 6, 12, 24], window_size=7, ape=True, drop_path_rate=0.0,
+               pano_mode=True)
+    torch.manual_seed(0)
+    m = SimplePanoSwinTransformer(**cfg, compute_dtype=torch.bfloat16)
+    m.init_weights(None)
+    m = m.cuda().train()
+    x = torch.randn(2, 3, 256, 512, device="cuda")
+    with torch.no_grad():
+        ws = [torch.randn_like(o).flatten() / o.numel() for o in m(x)]
+
+    def backward():
+        sum(o.float().flatten() @ w for o, w in zip(m(x), ws)).backward()
+
+    backward()
+    ref = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+    red = GradReducer(m, pack=True)
+    prev = ops.set_deferred_reductions(True)
+    try:
+        for _ in range(2):                                   # twice: the slots are handed out again every pass
+            red.zero_grad()
+            backward()
+            aliased = [k for k, p in m.named_parameters() if p.grad is not None and p.grad.data_ptr() == p._grad_slot.data_ptr()]
+            assert len(aliased) >= 20 and all(k.endswith("weight") for k in aliased), aliased
+            red.pack_grads()
+            red.finish()
+            for k, p in m.named_parameters():
+                assert p.grad.data_ptr() == p._grad_slot.data_ptr()
+                assert torch.equal(p.grad, ref[k]), k
+    finally:
+        ops.set_deferred_reductions(prev)
+
+
 def test_two_piece_backward_equals_plain_backward():
     """dp.backward_late + dp.backward_early (the step that overlaps the gradient all-reduce with the early layers'
     backward) produce the gradients of one plain backward pass."""
