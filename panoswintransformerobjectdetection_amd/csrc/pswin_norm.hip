@@ -160,18 +160,23 @@ __global__ __launch_bounds__(THREADS) void ln_bwd_kernel(const void* __restrict_
         const size_t img_in = (size_t)b * rs.S * (MODE == 0 ? C : C / 4);
         const float mu = mean[row], rs_ = rstd[row];
         const float rsc = (RSUM && res_scale) ? res_scale[b] : 1.0f;
-        f32x4 xh[NCH], g[NCH];
+        f32x4 xh[NCH], g[NCH], rv[NCH];
         long long offs[NCH];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             const int ch = lane + k * L;
-            xh[k] = g[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            xh[k] = g[k] = rv[k] = f32x4{0.f, 0.f, 0.f, 0.f};
             offs[k] = -1;
             if (ch < nchunks) {
                 offs[k] = src_offset<MODE>(rs, r, ch, C, r);
                 f32x4 xv = {0.f, 0.f, 0.f, 0.f};
-                if (offs[k] >= 0) xv = load4<XDT>(x, img_in + (size_t)offs[k]);
+                if (offs[k] >= 0) {
+                    xv = load4<XDT>(x, img_in + (size_t)offs[k]);
+                    // the shortcut gradient is requested together with the other two streams (it is only needed
+                    // after the row reductions; loading it there exposed its latency)
+                    if (dres) rv[k] = *reinterpret_cast<const f32x4*>(dres + img_in + (size_t)offs[k]);
+                }
                 const f32x4 dyv = load4<DYDT>(dy, dy_row * C + 4 * (size_t)ch);
                 const f32x4 g4 = *reinterpret_cast<const f32x4*>(gamma + 4 * ch);
                 xh[k] = (xv - mu) * rs_;
@@ -191,9 +196,8 @@ __global__ __launch_bounds__(THREADS) void ln_bwd_kernel(const void* __restrict_
                 f32x4 v = (g[k] - s1 - xh[k] * s2) * rs_;
                 // the gradient that reaches x along the residual shortcut, added here instead of in a separate pass
                 if (dres) {
-                    const f32x4 rv = *reinterpret_cast<const f32x4*>(dres + img_in + (size_t)offs[k]);
-                    v = v + rv;
-                    if constexpr (RSUM) dr[k] = dr[k] + rv * rsc;
+                    v = v + rv[k];
+                    if constexpr (RSUM) dr[k] = dr[k] + rv[k] * rsc;
                 }
                 store4<XDT>(dx, img_in + (size_t)offs[k], v);
             }
