@@ -138,6 +138,17 @@ int pswin_ln_gather_bwd(const void* dy, int dy_dtype, const int32_t* inv, const 
                         float* dres_sum, void* dx, float* dgamma, float* dbeta, float* workspace, int B, int S, int n_out,
                         int C, void* stream);
 
+/* window_scatter_add followed at once by a token-order LayerNorm (the attention half of a block, HOT:516-536:
+ * x1 = shortcut + DropPath(window_reverse(proj out) + proj bias), then norm2(x1)) in ONE pass:
+ *   x1[b][t] = resid[b][t] + scale[b] * (win[b][inv[t]] + bias);   y[b][t] = LN(x1[b][t]) * gamma + beta
+ * win: [B, n_slots, C] win_dtype; inv: int32 [S] or NULL (identity, n_slots == S); resid, x1: f32 [B, S, C]; scale: f32 [B]
+ * or NULL; bias: f32 [C] or NULL; y: [B, S, C] y_dtype; mean, rstd: f32 [B, S].  Bitwise the result of
+ * pswin_window_scatter_add + pswin_ln_gather_fwd; the backward pass is pswin_ln_gather_bwd + pswin_window_gather.
+ * C % 8 == 0, C <= 1024. */
+int pswin_scatter_add_ln_fwd(const void* win, int win_dtype, const int32_t* inv, const float* resid, const float* scale,
+                             const float* bias, float* x1, const float* gamma, const float* beta, float eps, void* y,
+                             int y_dtype, float* mean, float* rstd, int B, int S, int n_slots, int C, void* stream);
+
 /* Output norms: y = LayerNorm(x) written channel-major, i.e. norm{i}(x).view(B, H, W, C).permute(0, 3, 1, 2).contiguous()
  * of HOT:975-977 in one pass (x: f32 [B, S, C]; y: f32 [B, C, S]; mean, rstd: f32 [B, S]), and its backward from the
  * NCHW gradient dy f32 [B, C, S] (dres as in pswin_ln_gather_bwd; workspace: pswin_ln_workspace(B * S, C) elements).

@@ -220,10 +220,15 @@ class PanoSwinTransformerBlock(nn.Module, DoubleModeModule):
         att = ops.window_attention(qkv, a.sphere_position_alpha_table_Te, a.sphere_position_beta_table_Te, dist, mask,
                                    a.num_heads, a.scale, nW)
         att = _linear(att, a.proj, cd, use_bias=not fuse).view(B, nW * WTOK, C)
-        x = ops.window_scatter_add(att, x, wmap, inv, s1, a.proj.bias if fuse else None, True)   # shortcut + DropPath(attn)
         n2 = self.norm2
-        h, x = ops.layer_norm_gather(x, n2.weight, n2.bias, n2.eps, out_dtype=cd, passthrough=True,
-                                     res_bias=self.mlp.fc2.bias if fuse else None, res_scale=s2)
+        if x.dtype == torch.float32 and C <= 1024:
+            # shortcut + DropPath(attn) and norm2 of the sum in one kernel (the sum is not read back by a LayerNorm pass)
+            h, x = ops.scatter_add_layer_norm(att, x, wmap, inv, s1, a.proj.bias if fuse else None, n2.weight, n2.bias,
+                                              n2.eps, cd, res_bias=self.mlp.fc2.bias if fuse else None, res_scale=s2)
+        else:
+            x = ops.window_scatter_add(att, x, wmap, inv, s1, a.proj.bias if fuse else None, True)
+            h, x = ops.layer_norm_gather(x, n2.weight, n2.bias, n2.eps, out_dtype=cd, passthrough=True,
+                                         res_bias=self.mlp.fc2.bias if fuse else None, res_scale=s2)
         y = self.mlp.forward_nobias2(h, cd) if fuse else self.mlp(h, cd)
         ident = ops.identity_map(S, dev)                                          # x + DropPath(mlp): one row kernel
         return ops.window_scatter_add(y, x, ident, ident, s2, self.mlp.fc2.bias if fuse else None, True)

@@ -126,6 +126,70 @@ __global__ __launch_bounds__(THREADS) void ln_fwd_kernel(const void* __restrict_
     }
 }
 
+// window_scatter_add + LayerNorm in token order, one pass (the attention half of a block ends with
+// x1 = x + DropPath(window_reverse(proj(.)) + b) and norm2(x1) follows at once, HOT:516-536):
+//   x1[b][t] = resid[b][t] + scale[b] * (win[b][inv[t]] + bias);   y[b][t] = LN(x1[b][t]) * gamma + beta
+// x1 is written for the shortcut and the backward pass, but not read back by a separate LayerNorm kernel.  The
+// arithmetic (and its order) is that of window_scatter_add_kernel followed by ln_fwd_kernel: bitwise the same result.
+template <int WDT, int YDT, int L, int NCH>
+__global__ __launch_bounds__(THREADS) void ln_add_fwd_kernel(const void* __restrict__ win, const int32_t* __restrict__ inv,
+                                                             const float* __restrict__ resid, const float* __restrict__ scale,
+                                                             const float* __restrict__ bias, float* __restrict__ x1,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float eps, void* __restrict__ y, float* __restrict__ mean,
+                                                             float* __restrict__ rstd, long long rows, int S, int n_slots,
+                                                             int C) {
+    constexpr int RPB = THREADS / L;
+    const int lane = threadIdx.x % L;
+    const long long row = (long long)blockIdx.x * RPB + threadIdx.x / L;
+    if (row >= rows) return;
+    const int b = (int)(row / S);
+    const int t = (int)(row - (long long)b * S);
+    const int nchunks = C / 4;
+    const size_t wrow = ((size_t)b * n_slots + (inv ? inv[t] : t)) * C;
+    const float sc = scale ? scale[b] : 1.0f;
+    f32x4 v[NCH];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int ch = lane + k * L;
+        v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ch < nchunks) {
+            f32x4 val = load4<WDT>(win, wrow + 4 * (size_t)ch);
+            if (bias) val = val + *reinterpret_cast<const f32x4*>(bias + 4 * (size_t)ch);
+            if (scale) val = val * sc;
+            val = val + *reinterpret_cast<const f32x4*>(resid + (size_t)row * C + 4 * (size_t)ch);
+            *reinterpret_cast<f32x4*>(x1 + (size_t)row * C + 4 * (size_t)ch) = val;
+            v[k] = val;
+            s += (val[0] + val[1]) + (val[2] + val[3]);
+        }
+    }
+    const float mu = row_sum<L>(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int ch = lane + k * L;
+        if (ch < nchunks) {
+            const f32x4 d = v[k] - mu;
+            q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+        }
+    }
+    const float rs_ = rsqrtf(row_sum<L>(q) / (float)C + eps);
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int ch = lane + k * L;
+        if (ch < nchunks) {
+            const f32x4 g4 = *reinterpret_cast<const f32x4*>(gamma + 4 * ch);
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(beta + 4 * ch);
+            store4<YDT>(y, (size_t)row * C + 4 * (size_t)ch, (v[k] - mu) * rs_ * g4 + b4);
+        }
+    }
+    if (lane == 0) {
+        mean[row] = mu;
+        rstd[row] = rs_;
+    }
+}
+
 // Backward.  MODE 0 walks source tokens (b, t): dy row = dy[b][inv ? inv[t] : t].  MODE 1 walks merged rows and
 // scatters the 4 quarters of dx back to their tokens.  dgamma / dbeta: per-block partial sums, fixed order.
 // RSUM: also accumulate sum_rows res_scale[b] * dres[row] (the bias gradient of the Linear whose output, plus bias, was
@@ -539,6 +603,36 @@ extern "C" int pswin_ln_gather_fwd(const void* x, int x_dtype, const int32_t* ma
     return dispatch2(x_dtype, y_dtype, [&](auto xd, auto yd) {
         return launch_fwd<0, decltype(xd)::value, decltype(yd)::value>(L, x, rs, gamma, beta, eps, y, mean, rstd, rows,
                                                                        C, (hipStream_t)stream);
+    });
+}
+
+extern "C" int pswin_scatter_add_ln_fwd(const void* win, int win_dtype, const int32_t* inv, const float* resid,
+                                        const float* scale, const float* bias, float* x1, const float* gamma,
+                                        const float* beta, float eps, void* y, int y_dtype, float* mean, float* rstd, int B,
+                                        int S, int n_slots, int C, void* stream) {
+    PSWIN_CHECK_ARG(win && resid && x1 && gamma && beta && y && mean && rstd && B > 0 && S > 0 && n_slots > 0);
+    PSWIN_CHECK_ARG(valid_dtype(win_dtype) && valid_dtype(y_dtype) && (inv || n_slots == S));
+    PSWIN_CHECK_ARG(C >= 8 && C % 8 == 0 && C <= 1024 && aligned16(win) && aligned16(resid) && aligned16(x1) && aligned16(y));
+    PSWIN_CHECK_ARG(aligned16(gamma) && aligned16(beta) && aligned16(bias));
+    const long long rows = (long long)B * S;
+    const int L = pick_lanes(C);
+    hipStream_t st = (hipStream_t)stream;
+    return dispatch2(win_dtype, y_dtype, [&](auto wd, auto yd) {
+#define PSWIN_LN_ADD(LL)                                                                                                   \
+    case LL: {                                                                                                             \
+        const int rpb = THREADS / LL;                                                                                      \
+        hipLaunchKernelGGL((ln_add_fwd_kernel<decltype(wd)::value, decltype(yd)::value, LL, 4>),                            \
+                           dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(THREADS), 0, st, win, inv, resid, scale, bias, x1, \
+                           gamma, beta, eps, y, mean, rstd, rows, S, n_slots, C);                                          \
+        break;                                                                                                             \
+    }
+        switch (L) {
+            PSWIN_LN_ADD(2) PSWIN_LN_ADD(4) PSWIN_LN_ADD(8) PSWIN_LN_ADD(16) PSWIN_LN_ADD(32) PSWIN_LN_ADD(64)
+            default: return (int)PSWIN_ERR_ARG;
+        }
+#undef PSWIN_LN_ADD
+        hipError_t e__ = hipGetLastError();
+        return e__ == hipSuccess ? (int)PSWIN_OK : (int)e__;
     });
 }
 

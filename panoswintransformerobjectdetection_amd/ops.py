@@ -374,6 +374,63 @@ def layer_norm_gather(x, gamma, beta, eps, wmap=None, inv=None, out_dtype=None, 
     return _LayerNormGather.apply(x, gamma, beta, eps, wmap, inv, out_dtype or x.dtype, passthrough, res_bias, res_scale)
 
 
+class _ScatterAddLayerNorm(torch.autograd.Function):
+    """window_scatter_add + token-order LayerNorm in one forward pass (pswin_scatter_add_ln_fwd); the backward pass is the
+    LayerNorm backward kernel (with the shortcut gradient folded in, as layer_norm_gather(passthrough=True)) followed by
+    the window gather of window_scatter_add's backward."""
+
+    @staticmethod
+    def forward(ctx, win, resid, wmap, inv, scale, bias, gamma, beta, eps, out_dtype, res_bias, res_scale):
+        B, S, C = resid.shape
+        if resid.dtype != torch.float32:
+            raise PswinError("scatter_add_layer_norm needs an fp32 residual stream")
+        win, resid = win.contiguous(), resid.contiguous()
+        x1 = torch.empty_like(resid)
+        y = torch.empty(B, S, C, dtype=out_dtype, device=resid.device)
+        mean = torch.empty(B, S, dtype=torch.float32, device=resid.device)
+        rstd = torch.empty_like(mean)
+        b = None if bias is None else bias.detach().float().contiguous()
+        call("pswin_scatter_add_ln_fwd", win, ptr(win), dtype_code(win), ptr(inv), ptr(resid), ptr(scale), ptr(b), ptr(x1),
+             ptr(gamma), ptr(beta), float(eps), ptr(y), dtype_code(y), ptr(mean), ptr(rstd), B, S, win.shape[1], C,
+             algo_bytes=B * S * C * (win.element_size() + 8 + y.element_size()))
+        ctx.save_for_backward(x1, gamma, mean, rstd, wmap, scale, res_scale)
+        ctx.win_dtype, ctx.want_res_sum = win.dtype, res_bias is not None
+        return y, x1
+
+    @staticmethod
+    def backward(ctx, dy, dres):
+        x1, gamma, mean, rstd, wmap, scale, res_scale = ctx.saved_tensors
+        B, S, C = x1.shape
+        if dy is None:
+            raise PswinError("scatter_add_layer_norm: the normalised output must be used")
+        if ctx.want_res_sum and dres is None:
+            raise PswinError("scatter_add_layer_norm(res_bias=...) needs the second output to be used as the shortcut")
+        dy = dy.contiguous()
+        dres = None if dres is None else dres.float().contiguous()
+        dx1 = torch.empty_like(x1)
+        lib = _lib.load()
+        ws = torch.empty(lib.pswin_ln_workspace(B * S, C), dtype=torch.float32, device=x1.device)
+        nseg = 3 if ctx.want_res_sum else 2
+        call("pswin_ln_gather_bwd", x1, ptr(dy), dtype_code(dy), None, ptr(x1), dtype_code(x1), ptr(mean), ptr(rstd),
+             ptr(gamma), ptr(dres), ptr(res_scale), ptr(dres) if ctx.want_res_sum else None, ptr(dx1), None, None, ptr(ws),
+             B, S, S, C, algo_bytes=B * S * C * (dy.element_size() + (2 if dres is None else 3) * 4))
+        sums = sum_rows(ws, lib.pswin_ln_partial_rows(B * S, C), nseg * C)
+        dres_sum = sums[2 * C:] if ctx.want_res_sum else None
+        dwin = _gather_raw(dx1, wmap, scale, wmap.numel(), ctx.win_dtype)          # window_scatter_add's backward
+        return dwin, dx1, None, None, None, None, sums[:C], sums[C:2 * C], None, None, dres_sum, None
+
+
+def scatter_add_layer_norm(win, resid, wmap, inv, scale, bias, gamma, beta, eps, out_dtype=None, res_bias=None,
+                           res_scale=None):
+    """(y, x1) with x1 = resid + scale_b * (window_reverse(win) + bias) and y = LayerNorm(x1): window_scatter_add(...,
+    bias_grad_elsewhere=True) followed by layer_norm_gather(x1, passthrough=True, res_bias=..., res_scale=...) as ONE
+    forward kernel (the shortcut sum is not re-read by a LayerNorm kernel).  x1 is the tensor to use for the next
+    shortcut.  The gradient of `bias` is not returned here (it comes from the LayerNorm that produced `resid` with
+    res_bias=bias); res_bias / res_scale as in layer_norm_gather."""
+    return _ScatterAddLayerNorm.apply(win, resid, wmap, inv, scale, bias, gamma, beta, eps, out_dtype or resid.dtype,
+                                      res_bias, res_scale)
+
+
 class _LayerNormNCHW(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps, H, W, passthrough):

@@ -469,6 +469,35 @@ def test_residual_bias_pair(ops, use_scale):
     assert torch.allclose(biasd.grad, res[0][4], rtol=1e-5, atol=1e-4)
 
 
+@pytest.mark.parametrize("C,wdt,use_scale", [(96, torch.bfloat16, True), (384, torch.bfloat16, False), (768, torch.float32, True)])
+def test_scatter_add_layer_norm_equals_the_two_kernel_path(ops, C, wdt, use_scale):
+    """scatter_add_layer_norm == window_scatter_add followed by layer_norm_gather(passthrough=True, res_bias=...):
+    forward outputs bit for bit (same arithmetic, one pass), every gradient equal (same backward kernels)."""
+    B, H, W = 2, 13, 25
+    wmap, inv, nW = ops.window_maps(True, H, W, 3, DEV)
+    win = det_uniform((B, nW * 49, C), "sl:w", 2.0).to(wdt)
+    x = det_uniform((B, H * W, C), "sl:x", 2.0)
+    gamma, beta = det_uniform((C,), "sl:g", 0.5, 1.0), det_uniform((C,), "sl:b", 0.5)
+    pbias, fbias = det_uniform((C,), "sl:pb", 0.5), det_uniform((C,), "sl:fb", 0.5)
+    s1 = torch.tensor([0.0, 1.25], device=DEV) if use_scale else None
+    s2 = torch.tensor([1.25, 1.25], device=DEV) if use_scale else None
+    gy, gx = det_uniform((B, H * W, C), "sl:gy").to(DEV), det_uniform((B, H * W, C), "sl:gx").to(DEV)
+    res = []
+    for fused in (False, True):
+        wd, xd = win.to(DEV).requires_grad_(True), x.to(DEV).requires_grad_(True)
+        gd, bd, pb, fb = [t.to(DEV).requires_grad_(True) for t in (gamma, beta, pbias, fbias)]
+        if fused:
+            y, x1 = ops.scatter_add_layer_norm(wd, xd, wmap, inv, s1, pb, gd, bd, 1e-5, wdt, res_bias=fb, res_scale=s2)
+        else:
+            x1 = ops.window_scatter_add(wd, xd, wmap, inv, s1, pb, True)
+            y, x1 = ops.layer_norm_gather(x1, gd, bd, 1e-5, out_dtype=wdt, passthrough=True, res_bias=fb, res_scale=s2)
+        ((y.float() * gy).sum() + (x1 * gx).sum()).backward()
+        res.append((y.detach(), x1.detach(), wd.grad, xd.grad, gd.grad, bd.grad, fb.grad))
+        assert pb.grad is None                                   # produced elsewhere (bias_grad_elsewhere)
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("H,W,C", [(8, 16, 96), (16, 32, 192), (4, 8, 768), (16, 32, 96)])
 @pytest.mark.parametrize("passthrough", [False, True])
 def test_layer_norm_nchw(ops, H, W, C, passthrough):
