@@ -43,7 +43,7 @@ sys.path.insert(0, ROOT)
 TCFG = dict(embed_dim=96, depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24], window_size=7, ape=True,
             drop_path_rate=0.2, pano_mode=True)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md; ~6.3 TB/s achievable)
-TIMED = ("pswin_attn_fwd", "pswin_attn_bwd", "pswin_window_gather", "pswin_window_scatter_add", "pswin_ln_gather_fwd",
+TIMED = ("pswin_attn_fwd", "pswin_attn_bwd", "pswin_window_gather", "pswin_window_scatter_add", "pswin_scatter_add_ln_fwd", "pswin_ln_gather_fwd",
          "pswin_ln_gather_bwd", "pswin_bias_gelu_fwd", "pswin_bias_gelu_bwd", "pswin_stem_conv2_fwd", "pswin_stem_conv3_fwd",
          "pswin_stem_conv3_bwd_stats", "pswin_stem_conv3_bwd_data", "pswin_stem_conv3_wgrad", "pswin_stem_conv2_wgrad",
          "pswin_stem_conv2_bwd")

@@ -404,8 +404,7 @@ int pswin_attn_table_grads(const float* dscore_sum, int n_tiles, int n_bias_wind
 
 /* The same for several attention modules at once.  stages: 1 = only the partial sums over the dScore tiles (into each
  * job's workspace; best issued right after pswin_attn_bwd while the tiles are still in the last-level cache), 2 = only
- * the final per-bin sums from the workspaces (parameter gradients, needed only when the backward pass is over: one
- * launch for all attention modules of the pass), 3 = both.  `jobs` is a HOST array; it is copied into the kernel
+ * the sum of those partials and the per-bin sums (one binning launch for all jobs), 3 = both.  `jobs` is a HOST array; it is copied into the kernel
  * arguments (32 jobs per launch).  Field meaning as the arguments of pswin_attn_table_grads. */
 typedef struct pswin_table_grad_job {
     const float* dscore_sum;

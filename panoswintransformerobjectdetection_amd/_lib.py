@@ -6,7 +6,7 @@ import os
 import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libpswin_hip.so")
+LIB_PATH = os.environ.get("PSWIN_LIB") or os.path.join(_PKG, "libpswin_hip.so")   # PSWIN_LIB: another build (A/B runs)
 
 F32, BF16 = 0, 1
 MODE_PLANAR, MODE_PANO = 0, 1
