@@ -399,12 +399,16 @@ int pswin_attn_bwd(const void* q, const void* k, const void* v, int ld_qkv, cons
  * planar mode: dalpha untouched); dalpha, dbeta: f32 [169, heads], overwritten.
  * workspace: f32, pswin_attn_table_grads_workspace(heads) elements. */
 int pswin_attn_table_grads_workspace(int heads);
+int pswin_attn_table_grads_partial_rows(int n_tiles, int heads);
 int pswin_attn_table_grads(const float* dscore_sum, int n_tiles, int n_bias_windows, const float* dist_tiles_t,
                            int n_dist, int heads, float* dalpha, float* dbeta, float* workspace, void* stream);
 
-/* The same for several attention modules at once.  stages: 1 = only the partial sums over the dScore tiles (into each
- * job's workspace; best issued right after pswin_attn_bwd while the tiles are still in the last-level cache), 2 = only
- * the sum of those partials and the per-bin sums (one binning launch for all jobs), 3 = both.  `jobs` is a HOST array; it is copied into the kernel
+/* The same for several attention modules at once.  stages: 1 = only the partial sums over the dScore tiles (best issued
+ * right after pswin_attn_bwd while the tiles are still in the last-level cache), 2 = only the sum of those partials
+ * and the per-bin sums (one binning launch for all jobs), 3 = both, 4 = only the per-bin sums: the caller has summed
+ * the partial rows itself, e.g. as pswin_reduce_jobs jobs together with the other parameter-gradient reductions of
+ * the backward pass.  Workspace layout for that: pswin_attn_table_grads_partial_rows(n_tiles, heads) rows of
+ * ld = pswin_attn_table_grads_workspace(heads) / 129 floats from the start, their sum (ld floats) at offset 128 * ld.  `jobs` is a HOST array; it is copied into the kernel
  * arguments (32 jobs per launch).  Field meaning as the arguments of pswin_attn_table_grads. */
 typedef struct pswin_table_grad_job {
     const float* dscore_sum;

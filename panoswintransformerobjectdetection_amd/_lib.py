@@ -70,6 +70,7 @@ _PROTOTYPES = {
     "pswin_colsum": [_vp, _i, ctypes.c_longlong, _i, _vp, _vp, _vp],
     "pswin_reduce_jobs": [_vp, _i, _vp],
     "pswin_attn_table_grads_batch": [_vp, _i, _i, _vp],
+    "pswin_attn_table_grads_partial_rows": [_i, _i],
     "pswin_ln_partial_rows": [ctypes.c_longlong, _i],
     "pswin_bias_gelu_partial_rows": [ctypes.c_longlong, _i, _i],
     "pswin_fc1_gelu_partial_rows": [ctypes.c_longlong],

@@ -987,6 +987,16 @@ __global__ void pad_tiles_kernel(const float* __restrict__ src, int n, int trans
 }
 
 constexpr int DTAB_BLOCKS = 128;
+// floats per partial row [heads][2][49*49], rounded up to 4 so that rows stay 16-byte aligned (the row sum of the
+// partials can then run as a pswin_reduce_jobs job together with the other reductions of a backward pass)
+__host__ __device__ inline int dtab_ld(int heads) { return (heads * 2 * TOK * TOK + 3) & ~3; }
+// stage-1 workgroups per head: enough (blocks x heads >= ~500) to fill the chip, few enough to keep the partials small
+inline int dtab_blocks(int n_tiles, int heads) {
+    int nb = (512 + heads - 1) / heads;
+    if (nb > DTAB_BLOCKS) nb = DTAB_BLOCKS;
+    if (nb < 16) nb = 16;
+    return n_tiles < nb ? n_tiles : nb;
+}
 constexpr int DTAB_THREADS = 256;
 constexpr int DTAB_EPT = (TOK * TOK + DTAB_THREADS - 1) / DTAB_THREADS;   // 10 (i, j) pairs per thread
 
@@ -1038,7 +1048,7 @@ __global__ __launch_bounds__(DTAB_THREADS) void dtab_partial_kernel(const TBatch
             }
         }
     }
-    float* out = b.job[jn].partial + ((size_t)blk * heads + h) * 2 * TOK * TOK;
+    float* out = b.job[jn].partial + (size_t)blk * dtab_ld(heads) + (size_t)h * 2 * TOK * TOK;
 #pragma unroll
     for (int k = 0; k < DTAB_EPT; ++k) {
         const int e = threadIdx.x + k * DTAB_THREADS;
@@ -1161,8 +1171,12 @@ extern "C" int pswin_attn_suggest_chunks(int n_windows, int n_bias_windows, int 
     return pick_chunks(n_windows / n_bias_windows, n_bias_windows, heads, backward != 0);
 }
 
+extern "C" int pswin_attn_table_grads_partial_rows(int n_tiles, int heads) {
+    return (n_tiles > 0 && heads > 0) ? dtab_blocks(n_tiles, heads) : PSWIN_ERR_ARG;
+}
+
 extern "C" int pswin_attn_table_grads_workspace(int heads) {
-    return heads > 0 ? (DTAB_BLOCKS + 1) * heads * 2 * TOK * TOK : PSWIN_ERR_ARG;   // block partials + their sum
+    return heads > 0 ? (DTAB_BLOCKS + 1) * dtab_ld(heads) : PSWIN_ERR_ARG;   // block partial rows + their sum
 }
 
 extern "C" int pswin_attn_bwd(const void* q, const void* k, const void* v, int ld_qkv, const float* dist_t, int n_dist,
@@ -1199,7 +1213,7 @@ extern "C" int pswin_attn_bwd(const void* q, const void* k, const void* v, int l
 }
 
 extern "C" int pswin_attn_table_grads_batch(const pswin_table_grad_job* jobs, int n_jobs, int stages, void* stream) {
-    PSWIN_CHECK_ARG(jobs && n_jobs > 0 && stages >= 1 && stages <= 3);
+    PSWIN_CHECK_ARG(jobs && n_jobs > 0 && (stages == 1 || stages == 2 || stages == 3 || stages == 4));
     for (int j = 0; j < n_jobs; ++j) {
         const pswin_table_grad_job& q = jobs[j];
         PSWIN_CHECK_ARG(q.dscore_sum && q.dbeta && q.workspace && q.n_tiles > 0 && q.n_bias_windows > 0 && q.heads > 0);
@@ -1215,10 +1229,10 @@ extern "C" int pswin_attn_table_grads_batch(const pswin_table_grad_job* jobs, in
             TJob& t = b.job[j];
             // tiles are ordered (chunk, wb, h): tile x of head h belongs to bias window x % n_bias_windows
             t.g = q.dscore_sum; t.dist_t = q.dist_tiles_t; t.partial = q.workspace;
-            t.summed = q.workspace + (size_t)DTAB_BLOCKS * q.heads * 2 * TOK * TOK;
+            t.summed = q.workspace + (size_t)DTAB_BLOCKS * dtab_ld(q.heads);
             t.dalpha = q.dist_tiles_t ? q.dalpha : nullptr; t.dbeta = q.dbeta;
             t.n_tiles = q.n_tiles; t.nb = q.n_bias_windows; t.n_dist = q.dist_tiles_t ? q.n_dist : 1; t.heads = q.heads;
-            t.blocks = q.n_tiles < DTAB_BLOCKS ? q.n_tiles : DTAB_BLOCKS;
+            t.blocks = dtab_blocks(q.n_tiles, q.heads);
             t.first1 = (int)g1; t.first2 = (int)g2;
             g1 += (long long)t.blocks * q.heads;
             g2 += (NBINS * q.heads + 3) / 4;
@@ -1226,9 +1240,9 @@ extern "C" int pswin_attn_table_grads_batch(const pswin_table_grad_job* jobs, in
         PSWIN_CHECK_ARG(g1 < 0x7fffffffll && g2 < 0x7fffffffll);
         if (stages & 1)
             hipLaunchKernelGGL(dtab_partial_kernel, dim3((unsigned)g1), dim3(DTAB_THREADS), 0, (hipStream_t)stream, b);
-        if (stages & 2) {
-            for (int j = 0; j < b.n; ++j)
-                launch_colsum(b.job[j].partial, b.job[j].blocks, b.job[j].heads * 2 * TOK * TOK, b.job[j].summed, (hipStream_t)stream);
+        if (stages & 6) {
+            for (int j = 0; (stages & 2) && j < b.n; ++j)
+                launch_colsum(b.job[j].partial, b.job[j].blocks, dtab_ld(b.job[j].heads), b.job[j].summed, (hipStream_t)stream);
             hipLaunchKernelGGL(dtab_final_kernel, dim3((unsigned)g2), dim3(256), 0, (hipStream_t)stream, b);
         }
     }

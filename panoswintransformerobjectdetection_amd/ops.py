@@ -30,6 +30,7 @@ class _ReduceQueue:
     enabled = False
     task = -1            # autograd graph task the queued jobs belong to
     jobs = []            # (src tensor, byte offset, dtype code, rows, cols, ld, dst tensor)
+    table_jobs = []      # attention table gradients waiting for their binning launch (after the reductions)
     slot_task, slots = -2, set()    # flat-gradient slots already handed out in the current backward pass (grad_slot)
 
 
@@ -73,8 +74,11 @@ def _launch_table_grads(jobs, stages=3):
 def flush_reductions():
     """Issue the queued reductions now (runs by itself at the end of every backward pass that queued any)."""
     jobs, _ReduceQueue.jobs, _ReduceQueue.task = _ReduceQueue.jobs, [], -1
+    tjobs, _ReduceQueue.table_jobs = _ReduceQueue.table_jobs, []
     if jobs:
         _launch_reductions(jobs)
+    if tjobs:
+        _launch_table_grads(tjobs, 4)                   # per-bin sums from the partial-row sums the reductions just wrote
 
 
 def _deferring():
@@ -83,7 +87,7 @@ def _deferring():
     if task == -1:
         return False
     if _ReduceQueue.task != task:                       # first job of this pass (or leftovers of a pass that raised)
-        _ReduceQueue.jobs, _ReduceQueue.task = [], task
+        _ReduceQueue.jobs, _ReduceQueue.table_jobs, _ReduceQueue.task = [], [], task
         torch.autograd.Variable._execution_engine.queue_callback(flush_reductions)
     return True
 
@@ -820,9 +824,20 @@ class _WindowAttention(torch.autograd.Function):
             ws = torch.empty(lib.pswin_attn_table_grads_workspace(heads), dtype=torch.float32, device=x.device)
             job = (gsum, None if dist is None else dist.bwd, dalpha, dbeta, ws, chunks * nb, nb,
                    0 if dist is None else dist.n, heads)
-            # Not deferred to the end of the pass (unlike sum_rows): the dScore tiles and the block partials (together
-            # ~0.4 GB per step) are read while still in the last-level cache; postponing either stage measured slower.
-            _launch_table_grads([job])
+            # the sum over the dScore tiles runs now (they are still in the last-level cache); with deferred reductions
+            # the sum of its partial rows joins the grouped launch at the end of the pass and ONE binning launch serves
+            # all attention modules (same kernels, same order either way: bitwise equal results)
+            _launch_table_grads([job], 1)
+            ld = ws.numel() // 129
+            rjob = (ws, 0, F32, lib.pswin_attn_table_grads_partial_rows(chunks * nb, heads), ld, ld, ws[128 * ld:])
+            if _deferring():
+                _ReduceQueue.jobs.append(rjob)
+                _ReduceQueue.table_jobs.append(job)
+                dbeta = dbeta.view(169, heads)                       # fresh views: see sum_rows
+                dalpha = None if dalpha is None else dalpha.view(169, heads)
+            else:
+                _launch_reductions([rjob])
+                _launch_table_grads([job], 4)
         return dx, dk, dv, dalpha, dbeta, None, None, None, None, None, None
 
 
