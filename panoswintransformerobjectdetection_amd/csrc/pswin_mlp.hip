@@ -16,6 +16,7 @@ using namespace pswin;
 namespace {
 
 constexpr int THREADS = 256;
+constexpr int BWD_REP = 4;
 int g_unr_fwd = 2, g_unr_bwd = 4;             // row steps per block (pswin_bias_gelu_tune)
 
 template <int DT>
@@ -79,8 +80,12 @@ __global__ __launch_bounds__(THREADS) void bias_gelu_kernel(const void* __restri
     }
 #pragma unroll
     for (int e = 0; e < VE; ++e) acc[e] = 0.f;
-    if (rl < (unsigned)rps) {
-        const unsigned row0 = blockIdx.x * (UNR * rps) + rl;
+    // backward: REP batches of UNR row steps per block, so that the block's column-sum epilogue (LDS combine + one
+    // partial row) is paid once per REP * UNR * rps rows and the partial rows to be summed later are REP x fewer
+    constexpr int REP = BWD ? BWD_REP : 1;
+    if (rl < (unsigned)rps)
+      for (int rep = 0; rep < REP; ++rep) {
+        const unsigned row0 = (blockIdx.x * REP + rep) * (UNR * rps) + rl;
         float yv[UNR][VE], dh[BWD ? UNR : 1][VE];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
@@ -141,7 +146,7 @@ int launch_u(const void* a, const void* y, int dtype, const float* bias, void* o
     const int ve = dtype == PSWIN_BF16 ? 8 : 4;
     const int groups = N / ve, gw = pick_gw(groups);
     const int rps = THREADS / gw;
-    const long long bx = row_blocks(M, rps, UNR);
+    const long long bx = row_blocks(M, rps, UNR * (BWD ? BWD_REP : 1));
     if (bx > 0x7fffffffll || M * N >= 0x7fffffffll) return PSWIN_ERR_ARG;
     if (blocks_out) *blocks_out = (int)bx;
     dim3 grid((unsigned)bx, groups / gw);
@@ -202,7 +207,7 @@ int pswin_bias_gelu_partial_rows(long long M, int N, int dtype) {
     if (M <= 0 || N <= 0 || N % 8 || !valid_dtype(dtype)) return PSWIN_ERR_ARG;
     const int gw = pick_gw(N / (dtype == PSWIN_BF16 ? 8 : 4));
     const int unr = g_unr_bwd == 1 ? 1 : (g_unr_bwd == 2 ? 2 : 4);
-    const long long bx = row_blocks(M, THREADS / gw, unr);
+    const long long bx = row_blocks(M, THREADS / gw, unr * BWD_REP);
     return bx > 0x7fffffffll ? PSWIN_ERR_ARG : (int)bx;
 }
 
