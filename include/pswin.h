@@ -315,6 +315,11 @@ int pswin_fc1_gelu_bwd(const void* x, const void* w, const float* bias, const vo
 int pswin_colsum_workspace(long long M, int N, int dtype);
 int pswin_colsum(const void* x, int dtype, long long M, int N, float* out, float* workspace, void* stream);
 /* out == NULL: first stage only; pswin_colsum_workspace(M, N, dtype) / N partial rows of N sums stay in workspace. */
+/* First stage only, for a matrix whose columns [skip_lo, skip_hi) are known to sum to zero: they are not read and their
+ * partial sums are zeros.  Used for the qkv bias gradient (autograd of HOT:236, 287): the K third of d(qkv) sums to zero
+ * over the window tokens analytically (dK = dS^T Q and every row of dS sums to 0 because softmax rows sum to 1), so a
+ * third of the largest gradient tensor of each block is not re-read.  skip_lo, skip_hi: multiples of 8 (bf16) / 4 (f32). */
+int pswin_colsum_skip(const void* x, int dtype, long long M, int N, int skip_lo, int skip_hi, float* workspace, void* stream);
 
 /* Grouped column sums: dst[c] = sum_{r < rows} src[r * ld + c], c < cols, for up to a few hundred independent jobs in
  * ONE launch per 96 jobs (fixed summation order, bitwise reproducible).  The autograd of the path produces ~120 small

@@ -68,6 +68,7 @@ _PROTOTYPES = {
     "pswin_bias_gelu_bwd": [_vp, _vp, _i, _vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _vp],
     "pswin_colsum_workspace": [ctypes.c_longlong, _i, _i],
     "pswin_colsum": [_vp, _i, ctypes.c_longlong, _i, _vp, _vp, _vp],
+    "pswin_colsum_skip": [_vp, _i, ctypes.c_longlong, _i, _i, _i, _vp, _vp],
     "pswin_reduce_jobs": [_vp, _i, _vp],
     "pswin_attn_table_grads_batch": [_vp, _i, _i, _vp],
     "pswin_attn_table_grads_partial_rows": [_i, _i],

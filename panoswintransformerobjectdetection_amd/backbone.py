@@ -127,12 +127,13 @@ class _LinearSplitK(torch.autograd.Function):
     explicit split-K, 55-75 us) whose fp32 partial sum also removes the bf16 -> fp32 gradient cast."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, w_lp, b_lp):
+    def forward(ctx, x, weight, bias, w_lp, b_lp, zero_bias_cols=None):
         # w_lp / b_lp: this step's bf16 copies of the fp32 master parameters (refreshed by ONE multi-tensor cast per
         # forward, see SimplePanoSwinTransformer._refresh_lowp); gradients go to the fp32 masters.
         wb = w_lp if w_lp is not None else weight.to(x.dtype)
         ctx.save_for_backward(x, wb)
         ctx.has_bias = bias is not None
+        ctx.zero_bias_cols = zero_bias_cols
         ctx.weight = weight                                 # for ops.grad_slot: dW may be summed straight into its flat slot
         if ops.skinny_gemm_supported(x, wb.shape[0]):       # stage-0 shapes: streaming HIP GEMM, weight resident in LDS
             return ops.skinny_gemm(x, wb, bias)
@@ -159,13 +160,14 @@ class _LinearSplitK(torch.autograd.Function):
             dw = ops.sum_rows(part, ch, N * K, out=ops.grad_slot(ctx.weight)).view(N, K)
         else:
             dw = (dy.t() @ x).float()
-        db = ops.colsum(dy) if ctx.has_bias else None
-        return dx, dw, db, None, None
+        db = ops.colsum(dy, ctx.zero_bias_cols) if ctx.has_bias else None
+        return dx, dw, db, None, None, None
 
 
-def _linear(x, lin, cd, use_bias=True):
+def _linear(x, lin, cd, use_bias=True, zero_bias_cols=None):
     """nn.Linear on rows.  fp32: F.linear (parity path).  bf16: split-K weight gradient, fp32 parameter gradients.
-    use_bias=False: the caller applies lin.bias itself (fused into the next row kernel)."""
+    use_bias=False: the caller applies lin.bias itself (fused into the next row kernel).  zero_bias_cols=(lo, hi): output
+    columns whose gradient sums to zero over the rows (their bias gradient is zero; the column sum skips them)."""
     if cd == torch.float32:
         return F.linear(x.float(), lin.weight, lin.bias if use_bias else None)
     shp = x.shape
@@ -173,7 +175,8 @@ def _linear(x, lin, cd, use_bias=True):
     lp = lin.__dict__.get("_lowp")
     w_lp, b_lp = lp if lp is not None else (None, None)
     bias = lin.bias if use_bias else None
-    return _LinearSplitK.apply(x2, lin.weight, bias, w_lp, b_lp if use_bias else None).view(*shp[:-1], lin.weight.shape[0])
+    return _LinearSplitK.apply(x2, lin.weight, bias, w_lp, b_lp if use_bias else None,
+                               zero_bias_cols).view(*shp[:-1], lin.weight.shape[0])
 
 
 class PanoSwinTransformerBlock(nn.Module, DoubleModeModule):
@@ -216,7 +219,8 @@ class PanoSwinTransformerBlock(nn.Module, DoubleModeModule):
         # the second result is x itself: using it for the shortcut folds the shortcut's gradient into the LN backward kernel
         win, x = ops.layer_norm_gather(x, n1.weight, n1.bias, n1.eps, wmap, inv, cd, passthrough=True,
                                        res_bias=a.proj.bias if fuse else None, res_scale=s1)   # [B, nW*49, C]
-        qkv = _linear(win.view(-1, C), a.qkv, cd)                                 # [B*nW*49, 3C]
+        # the K third of d(qkv) sums to zero over every window (rows of dS sum to 0): its bias gradient is not summed
+        qkv = _linear(win.view(-1, C), a.qkv, cd, zero_bias_cols=(C, 2 * C))      # [B*nW*49, 3C]
         att = ops.window_attention(qkv, a.sphere_position_alpha_table_Te, a.sphere_position_beta_table_Te, dist, mask,
                                    a.num_heads, a.scale, nW)
         att = _linear(att, a.proj, cd, use_bias=not fuse).view(B, nW * WTOK, C)

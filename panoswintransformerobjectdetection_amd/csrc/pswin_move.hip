@@ -271,7 +271,8 @@ namespace {
 
 template <int DT>
 __global__ __launch_bounds__(256) void rowsum_partial_kernel(const void* __restrict__ x, long long M, int N,
-                                                             int vpr, int vprb, float* __restrict__ part) {
+                                                             int vpr, int vprb, float* __restrict__ part,
+                                                             int skip_lo = 0, int skip_hi = 0) {
     constexpr int VE = (DT == PSWIN_BF16) ? 8 : 4;        // elements per 16-byte vector
     __shared__ float red[256 * VE];
     const int rpi = 256 / vprb;                           // rows per iteration of this block
@@ -280,7 +281,8 @@ __global__ __launch_bounds__(256) void rowsum_partial_kernel(const void* __restr
     float acc[VE];
 #pragma unroll
     for (int e = 0; e < VE; ++e) acc[e] = 0.f;
-    if (rl < rpi && cg < vpr) {
+    // column groups [skip_lo, skip_hi) are known to sum to zero (see pswin_colsum_skip): not read, zeros written
+    if (rl < rpi && cg < vpr && !(cg >= skip_lo && cg < skip_hi)) {
         for (long long r = (long long)blockIdx.x * rpi + rl; r < M; r += (long long)gridDim.x * rpi) {
             if constexpr (DT == PSWIN_BF16) {
                 const u32x4 raw = *reinterpret_cast<const u32x4*>(reinterpret_cast<const unsigned short*>(x) +
@@ -403,6 +405,24 @@ extern "C" int pswin_colsum(const void* x, int dtype, long long M, int N, float*
         hipLaunchKernelGGL(rowsum_partial_kernel<PSWIN_F32>, dim3(blocks, ychunks), dim3(256), 0, (hipStream_t)stream,
                            x, M, N, vpr, vprb, workspace);
     if (out) launch_colsum(workspace, blocks, N, out, (hipStream_t)stream);     // else: partial rows only
+    PSWIN_LAUNCH_RET();
+}
+
+extern "C" int pswin_colsum_skip(const void* x, int dtype, long long M, int N, int skip_lo, int skip_hi, float* workspace,
+                                 void* stream) {
+    PSWIN_CHECK_ARG(x && workspace && M > 0 && N > 0 && valid_dtype(dtype) && N % 8 == 0 && aligned16(x));
+    const int ve = dtype == PSWIN_BF16 ? 8 : 4;
+    PSWIN_CHECK_ARG(skip_lo >= 0 && skip_lo <= skip_hi && skip_hi <= N && skip_lo % ve == 0 && skip_hi % ve == 0);
+    const int vpr = N / ve;
+    const int vprb = vpr < 256 ? vpr : 256;
+    const int ychunks = (vpr + vprb - 1) / vprb;
+    const int blocks = rowsum_blocks(M, N, dtype);
+    if (dtype == PSWIN_BF16)
+        hipLaunchKernelGGL(rowsum_partial_kernel<PSWIN_BF16>, dim3(blocks, ychunks), dim3(256), 0, (hipStream_t)stream,
+                           x, M, N, vpr, vprb, workspace, skip_lo / ve, skip_hi / ve);
+    else
+        hipLaunchKernelGGL(rowsum_partial_kernel<PSWIN_F32>, dim3(blocks, ychunks), dim3(256), 0, (hipStream_t)stream,
+                           x, M, N, vpr, vprb, workspace, skip_lo / ve, skip_hi / ve);
     PSWIN_LAUNCH_RET();
 }
 

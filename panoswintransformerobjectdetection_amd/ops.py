@@ -567,15 +567,19 @@ def batch_norm_relu(y, bn, training, pre_bias=None):
                                 pre_bias)
 
 
-def colsum(x2d):
-    """fp32 column sums of a [M, N] matrix (N % 8 == 0): bias gradients and split-K partial reductions."""
+def colsum(x2d, zero_cols=None):
+    """fp32 column sums of a [M, N] matrix (N % 8 == 0): bias gradients and split-K partial reductions.
+    zero_cols=(lo, hi): columns known to sum to zero (not read on the large-matrix path; see pswin_colsum_skip)."""
     x2d = x2d.contiguous()
     M, N = x2d.shape
     if M <= 4096:
         return sum_rows(x2d, M, N)
     n_ws = _lib.load().pswin_colsum_workspace(M, N, dtype_code(x2d))
     ws = torch.empty(n_ws, dtype=torch.float32, device=x2d.device)
-    call("pswin_colsum", x2d, ptr(x2d), dtype_code(x2d), M, N, None, ptr(ws))      # first stage: partial rows
+    if zero_cols is None:
+        call("pswin_colsum", x2d, ptr(x2d), dtype_code(x2d), M, N, None, ptr(ws))      # first stage: partial rows
+    else:
+        call("pswin_colsum_skip", x2d, ptr(x2d), dtype_code(x2d), M, N, int(zero_cols[0]), int(zero_cols[1]), ptr(ws))
     return sum_rows(ws, n_ws // N, N)
 
 

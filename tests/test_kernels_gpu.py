@@ -341,6 +341,11 @@ def test_colsum(ops, M, N, dt):
     ref = x.double().sum(0).float()
     got = ops.colsum(x.to(DEV)).cpu()
     assert torch.allclose(got, ref, rtol=1e-4, atol=1e-3)
+    if M > 4096 and N % 24 == 0:          # columns declared zero-sum are not read: zeros there, the rest unchanged
+        lo, hi = N // 3, 2 * N // 3
+        part = ops.colsum(x.to(DEV), zero_cols=(lo, hi)).cpu()
+        assert torch.equal(part[lo:hi], torch.zeros(hi - lo))
+        assert torch.equal(part[:lo], got[:lo]) and torch.equal(part[hi:], got[hi:])
 
 
 def test_grouped_reduction_many_jobs(ops):
