@@ -28,10 +28,17 @@ def clear_caches():
 # ------------------------------------------------------------------------------------------------
 class _ReduceQueue:
     enabled = False
-    task = -1            # autograd graph task the queued jobs belong to
-    jobs = []            # (src tensor, byte offset, dtype code, rows, cols, ld, dst tensor)
-    table_jobs = []      # attention table gradients waiting for their binning launch (after the reductions)
-    slot_task, slots = -2, set()    # flat-gradient slots already handed out in the current backward pass (grad_slot)
+    # autograd graph task id -> jobs queued by that backward pass.  Keyed by task because passes nest (the backward of a
+    # torch.utils.checkpoint segment is a pass of its own inside the outer one); each pass flushes its own jobs.
+    #   "jobs": (src tensor, byte offset, dtype code, rows, cols, ld, dst tensor)
+    #   "table_jobs": attention table gradients waiting for their binning launch (after the reductions)
+    tasks = {}
+    slots = {}           # graph task id -> flat-gradient slots already handed out in that pass (grad_slot)
+
+    @staticmethod
+    def trim(d):         # leftovers of passes that raised: keep the table small (task ids grow monotonically)
+        while len(d) > 8:
+            del d[min(d)]
 
 
 def set_deferred_reductions(on):
@@ -71,25 +78,31 @@ def _launch_table_grads(jobs, stages=3):
         call("pswin_attn_table_grads_batch", lst[0][0], ctypes.cast(arr, ctypes.c_void_p), len(lst), stages)
 
 
-def flush_reductions():
-    """Issue the queued reductions now (runs by itself at the end of every backward pass that queued any)."""
-    jobs, _ReduceQueue.jobs, _ReduceQueue.task = _ReduceQueue.jobs, [], -1
-    tjobs, _ReduceQueue.table_jobs = _ReduceQueue.table_jobs, []
-    if jobs:
-        _launch_reductions(jobs)
-    if tjobs:
-        _launch_table_grads(tjobs, 4)                   # per-bin sums from the partial-row sums the reductions just wrote
+def flush_reductions(task=None):
+    """Issue the reductions queued by one backward pass (runs by itself when that pass ends); task=None: all of them."""
+    keys = list(_ReduceQueue.tasks) if task is None else [task]
+    for k in keys:
+        q = _ReduceQueue.tasks.pop(k, None)
+        if q is None:
+            continue
+        if q["jobs"]:
+            _launch_reductions(q["jobs"])
+        if q["table_jobs"]:
+            _launch_table_grads(q["table_jobs"], 4)     # per-bin sums from the partial-row sums the reductions just wrote
 
 
 def _deferring():
-    """True inside a backward pass with deferred reductions on; arms the end-of-pass callback on first use."""
+    """The job queue of the running backward pass when deferred reductions are on (the end-of-pass callback is armed on
+    first use), else None."""
     task = torch._C._current_graph_task_id() if _ReduceQueue.enabled else -1
     if task == -1:
-        return False
-    if _ReduceQueue.task != task:                       # first job of this pass (or leftovers of a pass that raised)
-        _ReduceQueue.jobs, _ReduceQueue.table_jobs, _ReduceQueue.task = [], [], task
-        torch.autograd.Variable._execution_engine.queue_callback(flush_reductions)
-    return True
+        return None
+    q = _ReduceQueue.tasks.get(task)
+    if q is None:
+        q = _ReduceQueue.tasks[task] = {"jobs": [], "table_jobs": []}
+        _ReduceQueue.trim(_ReduceQueue.tasks)
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: flush_reductions(task))
+    return q
 
 
 def grad_slot(param):
@@ -101,11 +114,13 @@ def grad_slot(param):
     if slot is None or param.grad is not None or slot.device != param.device:
         return None
     task = torch._C._current_graph_task_id()
-    if _ReduceQueue.slot_task != task:
-        _ReduceQueue.slot_task, _ReduceQueue.slots = task, set()
-    if slot.data_ptr() in _ReduceQueue.slots:
+    used = _ReduceQueue.slots.get(task)
+    if used is None:
+        used = _ReduceQueue.slots[task] = set()
+        _ReduceQueue.trim(_ReduceQueue.slots)
+    if slot.data_ptr() in used:
         return None
-    _ReduceQueue.slots.add(slot.data_ptr())
+    used.add(slot.data_ptr())
     return slot
 
 
@@ -120,17 +135,19 @@ def sum_rows(src, rows, cols, ld=None, col_offset=0, out=None):
         if out.dtype != torch.float32 or out.numel() != cols or not out.is_contiguous():
             raise PswinError("sum_rows: `out` must be a contiguous float32 buffer of `cols` elements")
         job = (src, col_offset * src.element_size(), dtype_code(src), rows, cols, ld, out)
-        if _deferring():
-            _ReduceQueue.jobs.append(job)
+        q = _deferring()
+        if q is not None:
+            q["jobs"].append(job)
         else:
             _launch_reductions([job])
         return out.view(cols)
     out = torch.empty(cols, dtype=torch.float32, device=src.device)
     job = (src, col_offset * src.element_size(), dtype_code(src), rows, cols, ld, out)
-    if not _deferring():
+    q = _deferring()
+    if q is None:
         _launch_reductions([job])
         return out
-    _ReduceQueue.jobs.append(job)
+    q["jobs"].append(job)
     # the queue keeps `out` alive until the launch; hand autograd a fresh view so that AccumulateGrad can still adopt
     # the buffer as param.grad (it clones tensors that have other owners)
     return out.view(cols)
@@ -834,9 +851,10 @@ class _WindowAttention(torch.autograd.Function):
             _launch_table_grads([job], 1)
             ld = ws.numel() // 129
             rjob = (ws, 0, F32, lib.pswin_attn_table_grads_partial_rows(chunks * nb, heads), ld, ld, ws[128 * ld:])
-            if _deferring():
-                _ReduceQueue.jobs.append(rjob)
-                _ReduceQueue.table_jobs.append(job)
+            q = _deferring()
+            if q is not None:
+                q["jobs"].append(rjob)
+                q["table_jobs"].append(job)
                 dbeta = dbeta.view(169, heads)                       # fresh views: see sum_rows
                 dalpha = None if dalpha is None else dalpha.view(169, heads)
             else:
