@@ -55,6 +55,86 @@ __global__ void window_gather_kernel(const void* __restrict__ x, const int32_t* 
     }
 }
 
+// The two movers of the bf16 training step, 8 elements per thread and two rows per thread: one 16-byte access on the
+// bf16 side (the generic kernels above move 8 bytes per thread there), two on the f32 side, two independent rows in
+// flight.  Same arithmetic, element for element, as the generic kernels.
+//   gather8:  win[b][slot] = bf16(scale_b * x[b][map[slot]])          x: f32, win: bf16   (backward of scatter_add)
+//   scatter8: out[b][t] = resid[b][t] + scale_b * (win[b][inv[t]] + bias)   win: bf16, resid / out: f32
+__global__ __launch_bounds__(256) void window_gather8_kernel(const float* __restrict__ x, const int32_t* __restrict__ map,
+                                                             const float* __restrict__ scale,
+                                                             unsigned short* __restrict__ win, long long rows, int S,
+                                                             int n_slots, int lanes, int rpb) {
+    const int lane = threadIdx.x % lanes, rl = threadIdx.x / lanes;
+    if (rl >= rpb) return;
+    const size_t C = (size_t)lanes * 8;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const long long row = ((long long)blockIdx.x * 2 + u) * rpb + rl;
+        if (row >= rows) continue;
+        const int b = (int)(row / n_slots);
+        const int src = map[(int)(row - (long long)b * n_slots)];
+        u32x4 o = {0u, 0u, 0u, 0u};
+        if (src >= 0) {
+            const float* p = x + ((size_t)b * S + src) * C + 8 * (size_t)lane;
+            f32x4 a = *reinterpret_cast<const f32x4*>(p), c = *reinterpret_cast<const f32x4*>(p + 4);
+            if (scale) {
+                const float sc = scale[b];
+                a = a * sc;
+                c = c * sc;
+            }
+            o[0] = (unsigned)f32_to_bf16_bits(a[0]) | ((unsigned)f32_to_bf16_bits(a[1]) << 16);
+            o[1] = (unsigned)f32_to_bf16_bits(a[2]) | ((unsigned)f32_to_bf16_bits(a[3]) << 16);
+            o[2] = (unsigned)f32_to_bf16_bits(c[0]) | ((unsigned)f32_to_bf16_bits(c[1]) << 16);
+            o[3] = (unsigned)f32_to_bf16_bits(c[2]) | ((unsigned)f32_to_bf16_bits(c[3]) << 16);
+        }
+        *reinterpret_cast<u32x4*>(win + (size_t)row * C + 8 * (size_t)lane) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void window_scatter_add8_kernel(const unsigned short* __restrict__ win,
+                                                                  const int32_t* __restrict__ inv,
+                                                                  const float* __restrict__ resid,
+                                                                  const float* __restrict__ scale,
+                                                                  const float* __restrict__ bias, float* __restrict__ out,
+                                                                  long long rows, int S, int n_slots, int lanes, int rpb) {
+    const int lane = threadIdx.x % lanes, rl = threadIdx.x / lanes;
+    if (rl >= rpb) return;
+    const size_t C = (size_t)lanes * 8;
+    f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
+    if (bias) {
+        b0 = *reinterpret_cast<const f32x4*>(bias + 8 * lane);
+        b1 = *reinterpret_cast<const f32x4*>(bias + 8 * lane + 4);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const long long row = ((long long)blockIdx.x * 2 + u) * rpb + rl;
+        if (row >= rows) continue;
+        const int b = (int)(row / S);
+        const int slot = inv[(int)(row - (long long)b * S)];
+        const u32x4 raw = *reinterpret_cast<const u32x4*>(win + ((size_t)b * n_slots + slot) * C + 8 * (size_t)lane);
+        f32x4 a = {__builtin_bit_cast(float, raw[0] << 16), __builtin_bit_cast(float, raw[0] & 0xffff0000u),
+                   __builtin_bit_cast(float, raw[1] << 16), __builtin_bit_cast(float, raw[1] & 0xffff0000u)};
+        f32x4 c = {__builtin_bit_cast(float, raw[2] << 16), __builtin_bit_cast(float, raw[2] & 0xffff0000u),
+                   __builtin_bit_cast(float, raw[3] << 16), __builtin_bit_cast(float, raw[3] & 0xffff0000u)};
+        if (bias) {
+            a = a + b0;
+            c = c + b1;
+        }
+        if (scale) {
+            const float sc = scale[b];
+            a = a * sc;
+            c = c * sc;
+        }
+        const size_t o = (size_t)row * C + 8 * (size_t)lane;
+        if (resid) {
+            a = a + *reinterpret_cast<const f32x4*>(resid + o);
+            c = c + *reinterpret_cast<const f32x4*>(resid + o + 4);
+        }
+        *reinterpret_cast<f32x4*>(out + o) = a;
+        *reinterpret_cast<f32x4*>(out + o + 4) = c;
+    }
+}
+
 template <int WDT, int XDT>
 __global__ void window_scatter_add_kernel(const void* __restrict__ win, const int32_t* __restrict__ inv,
                                           const void* __restrict__ resid, const float* __restrict__ scale,
@@ -177,6 +257,12 @@ extern "C" int pswin_window_gather(const void* x, int x_dtype, const int32_t* ma
     RowGeom g = row_geom(C);
     long long rows = (long long)B * n_slots;
     PSWIN_CHECK_ARG(rows_ok(rows, g.rows_per_block));
+    if (x_dtype == PSWIN_F32 && win_dtype == PSWIN_BF16 && C / 8 <= 256) {
+        const int lanes = C / 8, rpb = 256 / lanes;
+        hipLaunchKernelGGL(window_gather8_kernel, dim3((unsigned)((rows + 2 * rpb - 1) / (2 * rpb))), dim3(256), 0,
+                           (hipStream_t)stream, (const float*)x, map, scale, (unsigned short*)win, rows, S, n_slots, lanes, rpb);
+        PSWIN_LAUNCH_RET();
+    }
     dim3 grid((unsigned)((rows + g.rows_per_block - 1) / g.rows_per_block));
     return dispatch2(x_dtype, win_dtype, [&](auto xd, auto wd) {
         hipLaunchKernelGGL((window_gather_kernel<decltype(xd)::value, decltype(wd)::value>), grid, g.block, 0,
@@ -194,6 +280,13 @@ extern "C" int pswin_window_scatter_add(const void* win, int win_dtype, const in
     RowGeom g = row_geom(C);
     long long rows = (long long)B * S;
     PSWIN_CHECK_ARG(rows_ok(rows, g.rows_per_block));
+    if (win_dtype == PSWIN_BF16 && x_dtype == PSWIN_F32 && C / 8 <= 256) {
+        const int lanes = C / 8, rpb = 256 / lanes;
+        hipLaunchKernelGGL(window_scatter_add8_kernel, dim3((unsigned)((rows + 2 * rpb - 1) / (2 * rpb))), dim3(256), 0,
+                           (hipStream_t)stream, (const unsigned short*)win, inv, (const float*)resid, scale, bias, (float*)out,
+                           rows, S, n_slots, lanes, rpb);
+        PSWIN_LAUNCH_RET();
+    }
     dim3 grid((unsigned)((rows + g.rows_per_block - 1) / g.rows_per_block));
     return dispatch2(win_dtype, x_dtype, [&](auto wd, auto xd) {
         hipLaunchKernelGGL((window_scatter_add_kernel<decltype(wd)::value, decltype(xd)::value>), grid, g.block, 0,
