@@ -998,7 +998,6 @@ inline int dtab_blocks(int n_tiles, int heads) {
     return n_tiles < nb ? n_tiles : nb;
 }
 constexpr int DTAB_THREADS = 256;
-constexpr int DTAB_EPT = (TOK * TOK + DTAB_THREADS - 1) / DTAB_THREADS;   // 10 (i, j) pairs per thread
 
 // Table-gradient jobs of one backward pass (one per attention module) run as TWO launches for all of them; the job table
 // travels in the kernel arguments.
@@ -1020,7 +1019,7 @@ struct TBatch {
 static_assert(sizeof(TBatch) <= 4000, "the job table must fit the kernel-argument segment");
 
 // Stage 1: per (block, head) of a job, sum over a strided subset of the tiles of g and g * d for every (i, j) pair.  A
-// thread owns the same 10 pairs for every tile, so the sums stay in registers (no atomics).
+// thread owns the same pairs for every tile, so the sums stay in registers (no atomics).
 __global__ __launch_bounds__(DTAB_THREADS) void dtab_partial_kernel(const TBatch b) {
     int jn = 0;
     for (int q = 1; q < b.n; ++q)
@@ -1031,30 +1030,41 @@ __global__ __launch_bounds__(DTAB_THREADS) void dtab_partial_kernel(const TBatch
     const int nblk = b.job[jn].blocks;
     const int local = (int)blockIdx.x - b.job[jn].first1;
     const int blk = local / heads, h = local - blk * heads;
-    float sb[DTAB_EPT], sa[DTAB_EPT];
+    // 16-byte loads: a thread owns up to 3 quads (j, 4 i4 .. 4 i4 + 3) of the 49 x 13 quads that hold real pairs (the
+    // 64 x 64 tiles are zero beyond 49 in both directions)
+    constexpr int QPR = (TOK + 3) / 4, NQ = TOK * QPR, QPT = (NQ + DTAB_THREADS - 1) / DTAB_THREADS;
+    f32x4 sb[QPT], sa[QPT];
+    int qoff[QPT];
 #pragma unroll
-    for (int k = 0; k < DTAB_EPT; ++k) sb[k] = sa[k] = 0.f;
+    for (int k = 0; k < QPT; ++k) {
+        sb[k] = sa[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int q = threadIdx.x + k * DTAB_THREADS;
+        qoff[k] = q < NQ ? (q / QPR) * PADT + 4 * (q % QPR) : -1;
+    }
     for (int tile = blk; tile < n_tiles; tile += nblk) {
         const float* gt = g + ((size_t)tile * heads + h) * (PADT * PADT);
         const float* dt = dist_t ? dist_t + (size_t)((tile % nb) % n_dist) * (PADT * PADT) : nullptr;
 #pragma unroll
-        for (int k = 0; k < DTAB_EPT; ++k) {
-            const int e = threadIdx.x + k * DTAB_THREADS;      // e = j * 49 + i: i contiguous in the tiles
-            if (e < TOK * TOK) {
-                const int j = e / TOK, i = e - j * TOK;
-                const float gval = gt[j * PADT + i];
-                sb[k] += gval;
-                if (dt) sa[k] += gval * dt[j * PADT + i];
+        for (int k = 0; k < QPT; ++k) {
+            if (qoff[k] >= 0) {
+                const f32x4 gval = *reinterpret_cast<const f32x4*>(gt + qoff[k]);
+                sb[k] = sb[k] + gval;
+                if (dt) sa[k] = sa[k] + gval * *reinterpret_cast<const f32x4*>(dt + qoff[k]);
             }
         }
     }
     float* out = b.job[jn].partial + (size_t)blk * dtab_ld(heads) + (size_t)h * 2 * TOK * TOK;
 #pragma unroll
-    for (int k = 0; k < DTAB_EPT; ++k) {
-        const int e = threadIdx.x + k * DTAB_THREADS;
-        if (e < TOK * TOK) {
-            out[e] = sb[k];
-            out[TOK * TOK + e] = sa[k];
+    for (int k = 0; k < QPT; ++k) {
+        if (qoff[k] >= 0) {
+            const int j = qoff[k] / PADT, i0 = qoff[k] - j * PADT;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (i0 + e < TOK) {
+                    out[j * TOK + i0 + e] = sb[k][e];
+                    out[TOK * TOK + j * TOK + i0 + e] = sa[k][e];
+                }
+            }
         }
     }
 }
