@@ -513,7 +513,10 @@ inline int pick_lanes(int C) {
 inline bool wide_row(int C) { return C > 1024; }
 constexpr int MAX_C = 2048;
 
-constexpr int BWD_MAX_BLOCKS = 1536;    // 6 blocks of 4 waves per CU: with 512 only 2 waves per SIMD were resident (3.4 TB/s)
+// Persistent grid of the backward kernels: exactly the resident capacity (256 CUs x 4 blocks of 4 waves at ~125 VGPRs).
+// 1536 blocks ran as 1.5 rounds (the last half round leaves half of the chip idle: -1.2 % end to end), 512 leave two
+// of the four wave slots per SIMD empty (3.4 TB/s).  The partial rows are summed by the grouped end-of-pass reduction.
+constexpr int BWD_MAX_BLOCKS = 1024;
 
 inline int bwd_blocks(long long rows, int L) {
     const int rpb = THREADS / L;
