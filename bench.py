@@ -151,11 +151,12 @@ def main():
 
     # Split backward (N > 1): stages 2-3 hold ~90 % of the parameters and their gradients are finished first.  The step
     # is captured as TWO graphs sharing one memory pool -- (forward + backward of stages 2-3 + pack) and (backward of
-    # stages 0-1 and the stem + pack) -- and the RCCL all-reduce of the late buckets is launched between the two replays,
-    # so it runs on xGMI under the second graph's kernels; only the small early buckets are exposed.  One xGMI link per
-    # GPU pair: at N = 2 the 112 MB all-reduce would otherwise add ~1.7 ms to a 14 ms step.
+    # stages 0-1 and the stem + pack) -- and the RCCL all-reduce of the late group's buckets (the reducer cuts its buckets
+    # at the group boundary: tests/test_dp_gloo.py asserts >= 90 % of the gradient bytes) is launched between the two
+    # replays, so it runs on xGMI under the second graph's kernels; only the early group's bucket is exposed.  One xGMI
+    # link per GPU pair: at N = 2 the 112 MB all-reduce would otherwise add ~1.7 ms to a 14 ms step.
     from panoswintransformerobjectdetection_amd.dp import BoundaryTap, backward_early, backward_late, split_parameters
-    late_params, early_params = split_parameters(model, ("layers.2.", "layers.3.", "norm2.", "norm3."))
+    late_params, early_params = split_parameters(model)          # = model.grad_groups(): the reducer's buckets follow it
     tap = BoundaryTap(model.layers[2])
     carry = {}
 

@@ -28,6 +28,8 @@ warnings.filterwarnings("ignore")
 TINY = dict(embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], ape=True, drop_path_rate=0.0)
 TINY_PITCH = dict(embed_dim=32, depths=[3, 2, 1, 2], num_heads=[1, 2, 4, 8], ape=True, drop_path_rate=0.0)
 TCFG = dict(embed_dim=96, depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24], ape=True, drop_path_rate=0.0)
+# PanoSwin-S: configs/swin/mask_rcnn_swin_small_patch4_window7_mstrain_480-800_adamw_3x_coco.py:10 (depths 2,2,18,2)
+SCFG = dict(embed_dim=96, depths=[2, 2, 18, 2], num_heads=[3, 6, 12, 24], ape=True, drop_path_rate=0.0)
 
 PANO_CASES = [(128, 256), (64, 128), (32, 64), (16, 32), (13, 25), (25, 49), (50, 99), (14, 28)]
 PLANAR_CASES = [(16, 32), (15, 31), (128, 256), (20, 33), (15, 25)]
@@ -180,21 +182,40 @@ def run_model(ns, cfg, pano, shape, tag, train=True, subsample_out=None):
 
 
 def main():
+    """python oracle/gen_golden.py [name ...]: regenerate the named fixtures (default: all of them)."""
     ns = ref_loader.load_reference()
     assert ns is not None, "the reference is not available here"
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    gen_index_maps(ns.hot)
-    gen_geometry(ns)
-    gen_window_attention(ns.hot)
-    save("tiny_pano", **run_model(ns, TINY, True, (2, 3, 64, 128), "tiny"))
-    save("tiny_planar", **run_model(ns, TINY, False, (2, 3, 64, 128), "tiny"))
-    save("tiny_planar_odd", **run_model(ns, TINY, False, (2, 3, 60, 100), "tiny"))
-    save("tiny_pano_oddw", **run_model(ns, TINY, True, (1, 3, 100, 196), "tiny"))
-    save("tiny_pitch_pano", as_shimmed=np.int32(1), **run_model(ns, TINY_PITCH, True, (2, 3, 64, 128), "tinyp"))
-    save("tiny_pitch_planar", as_shimmed=np.int32(1), **run_model(ns, TINY_PITCH, False, (2, 3, 60, 100), "tinyp"))
-    save("T_512x1024_pano", **run_model(ns, TCFG, True, (2, 3, 512, 1024), "T", subsample_out=4096))
+    jobs = {
+        "index_maps": lambda: gen_index_maps(ns.hot),
+        "geometry": lambda: gen_geometry(ns),
+        "window_attention": lambda: gen_window_attention(ns.hot),
+        "tiny_pano": lambda: save("tiny_pano", **run_model(ns, TINY, True, (2, 3, 64, 128), "tiny")),
+        "tiny_planar": lambda: save("tiny_planar", **run_model(ns, TINY, False, (2, 3, 64, 128), "tiny")),
+        "tiny_planar_odd": lambda: save("tiny_planar_odd", **run_model(ns, TINY, False, (2, 3, 60, 100), "tiny")),
+        "tiny_pano_oddw": lambda: save("tiny_pano_oddw", **run_model(ns, TINY, True, (1, 3, 100, 196), "tiny")),
+        "tiny_pitch_pano": lambda: save("tiny_pitch_pano", as_shimmed=np.int32(1),
+                                        **run_model(ns, TINY_PITCH, True, (2, 3, 64, 128), "tinyp")),
+        "tiny_pitch_planar": lambda: save("tiny_pitch_planar", as_shimmed=np.int32(1),
+                                          **run_model(ns, TINY_PITCH, False, (2, 3, 60, 100), "tinyp")),
+        # eval mode (BatchNorm running statistics, DropPath off): tiny models with all gradients, and BASELINE
+        # configs[0] = PanoSwin-T forward, batch 2, 512x1024 (its backward pass is stored too: eval-mode fine-tuning)
+        "tiny_pano_eval": lambda: save("tiny_pano_eval", **run_model(ns, TINY, True, (2, 3, 64, 128), "tiny", train=False)),
+        "tiny_planar_eval": lambda: save("tiny_planar_eval",
+                                         **run_model(ns, TINY, False, (2, 3, 60, 100), "tiny", train=False)),
+        "T_512x1024_pano": lambda: save("T_512x1024_pano",
+                                        **run_model(ns, TCFG, True, (2, 3, 512, 1024), "T", subsample_out=4096)),
+        "T_512x1024_pano_eval": lambda: save("T_512x1024_pano_eval", **run_model(ns, TCFG, True, (2, 3, 512, 1024), "T",
+                                                                                 train=False, subsample_out=4096)),
+        # BASELINE configs[4] geometry: PanoSwin-S on one 1024x2048 panorama (train mode, all gradients)
+        "S_1024x2048_pano": lambda: save("S_1024x2048_pano",
+                                         **run_model(ns, SCFG, True, (1, 3, 1024, 2048), "S", subsample_out=4096)),
+    }
+    names = sys.argv[1:] or list(jobs)
+    for n in names:
+        jobs[n]()
 
 
 if __name__ == "__main__":

@@ -134,7 +134,7 @@ class _LinearSplitK(torch.autograd.Function):
         ctx.save_for_backward(x, wb)
         ctx.has_bias = bias is not None
         ctx.zero_bias_cols = zero_bias_cols
-        ctx.weight = weight                                 # for ops.grad_slot: dW may be summed straight into its flat slot
+        ctx.weight, ctx.bias = weight, bias                 # for ops.grad_slot / owners: dW may be summed straight into its flat slot
         if ops.skinny_gemm_supported(x, wb.shape[0]):       # stage-0 shapes: streaming HIP GEMM, weight resident in LDS
             return ops.skinny_gemm(x, wb, bias)
         bb = None if bias is None else (b_lp if b_lp is not None else bias.to(x.dtype))
@@ -157,10 +157,10 @@ class _LinearSplitK(torch.autograd.Function):
         ch = _pick_split(M, -(-N // 64) * -(-K // 64))
         if ch > 1:
             part = torch.bmm(dy.view(ch, M // ch, N).transpose(1, 2), x.view(ch, M // ch, K))
-            dw = ops.sum_rows(part, ch, N * K, out=ops.grad_slot(ctx.weight)).view(N, K)
+            dw = ops.sum_rows(part, ch, N * K, out=ops.grad_slot(ctx.weight), owners=(ctx.weight,)).view(N, K)
         else:
             dw = (dy.t() @ x).float()
-        db = ops.colsum(dy, ctx.zero_bias_cols) if ctx.has_bias else None
+        db = ops.colsum(dy, ctx.zero_bias_cols, owners=(ctx.bias,)) if ctx.has_bias else None
         return dx, dw, db, None, None, None
 
 
@@ -365,6 +365,7 @@ class _ApeAdd(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, feat, weight, bias):
         ctx.save_for_backward(feat, weight)
+        ctx.bias = bias
         return x + F.linear(feat, weight, bias)[None]
 
     @staticmethod
@@ -372,7 +373,7 @@ class _ApeAdd(torch.autograd.Function):
         feat, weight = ctx.saved_tensors
         gs = g.sum(0) if g.shape[0] > 1 else g[0]              # [S, C]: a per-element sum over the batch (one pass)
         dw = gs.t() @ feat                                      # [C, 5]
-        db = ops.colsum(gs.contiguous())
+        db = ops.colsum(gs.contiguous(), owners=(ctx.bias,))
         return g, None, dw, db
 
 
@@ -498,6 +499,23 @@ class SimplePanoSwinTransformer(nn.Module, DoubleModeModule):
         self.pano_mode = pano_mode
         for layer in self.layers:
             layer.set_pano_mode(pano_mode)
+
+    LATE_STAGES = 2          # the stages from this index on form the first gradient group (dp.py: reduced under the rest)
+
+    def grad_groups(self):
+        """Trainable parameters in the order a backward pass finishes their gradients, as two groups for
+        dp.GradReducer / dp.split_parameters: [norm3, layers.3, norm2, layers.2] (90 % of the bytes; their all-reduce runs
+        under the backward pass of the second group) and [norm1, layers.1, norm0, layers.0, abs_encoder, patch_embed]."""
+        def stage(i):
+            ps = list(getattr(self, f"norm{i}").parameters()) if i in self.out_indices else []
+            return ps + list(reversed(list(self.layers[i].parameters())))
+        cut = min(self.LATE_STAGES, self.num_layers)
+        late = [p for i in range(self.num_layers - 1, cut - 1, -1) for p in stage(i)]
+        early = [p for i in range(cut - 1, -1, -1) for p in stage(i)]
+        if self.ape:
+            early += list(reversed(list(self.abs_encoder.parameters())))
+        early += list(reversed(list(self.patch_embed.parameters())))
+        return [[p for p in late if p.requires_grad], [p for p in early if p.requires_grad]]
 
     def init_weights(self, pretrained=None):
         """HOT:885-907."""

@@ -9,9 +9,11 @@ are never synchronised; parameters that received no gradient contribute zeros.
 MI355X-first choices
   * all gradients live in ONE flat fp32 buffer (``param.grad`` are views into it): zeroing is one memset, the
     optimizer can run over contiguous memory, and a bucket is just a slice -- no flatten / unflatten copies;
-  * buckets are cut in reverse registration order (the order backward produces gradients) and each is launched
-    as soon as its last gradient has been accumulated, from a post-accumulate hook, so RCCL runs on its own
-    stream under the remaining backward kernels;
+  * buckets are cut in the order backward finishes the gradients -- the module's ``grad_groups()`` when it defines one
+    (the backbone does: [stages 3-2 with their output norms | stages 1-0, position encoder, stem]), else reverse
+    registration order -- with a forced cut at every group boundary, so a bucket never mixes late and early layers;
+    each is launched as soon as its last gradient has been accumulated (post-accumulate hook) or, for the two-graph
+    step, as soon as its group's backward piece has been packed, so RCCL runs under the remaining backward kernels;
   * xGMI is a point-to-point mesh (7 links per GPU): few large messages beat many small ones, hence the default
     32 MiB buckets (4 launches for the 110 MB of PanoSwin-T gradients) and ``ReduceOp.AVG`` in the collective
     itself instead of a separate divide pass.
@@ -35,20 +37,41 @@ def init_distributed(backend=None):
     return rank, local_rank, world
 
 
+def completion_groups(module, groups=None):
+    """Trainable parameters of `module` as a list of groups in the order a backward pass finishes them.  groups: explicit
+    list of parameter lists; None: ``module.grad_groups()`` if defined, else one group in reverse registration order."""
+    if groups is None and hasattr(module, "grad_groups"):
+        groups = module.grad_groups()
+    params = [p for p in module.parameters() if p.requires_grad]
+    if groups is None:
+        return [list(reversed(params))]
+    groups = [[p for p in g if p.requires_grad] for g in groups]
+    seen = [id(p) for g in groups for p in g]
+    if len(set(seen)) != len(seen) or set(seen) != {id(p) for p in params}:
+        raise ValueError("grad groups must partition the module's trainable parameters")
+    return [g for g in groups if g]
+
+
 class GradReducer:
-    def __init__(self, module, bucket_mb=32.0, process_group=None, pack=False):
+    def __init__(self, module, bucket_mb=32.0, process_group=None, pack=False, groups=None):
         """pack=False: ``param.grad`` are views of the flat buffer and autograd accumulates into them (one small add
         kernel per parameter).  pack=True: gradients are produced as free tensors (``param.grad = None`` before
         backward) and gathered into the flat buffer by ONE multi-tensor copy in finish() -- fewer, larger launches;
-        meant for the hipGraph path where collectives run after backward anyway."""
+        meant for the hipGraph path where collectives run after backward anyway.
+        groups: see completion_groups; bucket boundaries are forced at group boundaries."""
         self.pack = pack
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        self.params = [p for p in module.parameters() if p.requires_grad]
+        self.groups = completion_groups(module, groups)
+        self.params = [p for g in self.groups for p in g]
         if not self.params:
             raise ValueError("no trainable parameters")
         dev = self.params[0].device
-        order = list(reversed(self.params))                       # ~ the order in which backward finishes them
+        order = self.params                                       # the order in which backward finishes them
+        group_end, n = set(), 0
+        for g in self.groups:
+            n += len(g)
+            group_end.add(n - 1)
         offsets, total = [], 0
         for p in order:
             offsets.append(total)
@@ -70,17 +93,17 @@ class GradReducer:
             self._bucket_of[p] = len(self.buckets)
             count += 1
             end = offsets[i + 1] if i + 1 < len(order) else total
-            if end - start >= limit or i + 1 == len(order):
+            if end - start >= limit or i in group_end:
                 self.buckets.append([start, end, count])
                 start, count = end, 0
+        self._index = {id(p): i for i, p in enumerate(order)}
         self._pending = [b[2] for b in self.buckets]
         self._launched = [False] * len(self.buckets)
         self._handles = []
         self.overlap = True          # launch buckets from backward hooks; set False to reduce everything in finish()
         self._use_avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         self.overlap = not pack
-        self._hooks = ([p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params]
-                       if self.world > 1 and not pack else [])
+        self._hooks = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self.params] if not pack else []
 
     # -- per step -----------------------------------------------------------------------------------------------
     def zero_grad(self):
@@ -133,17 +156,36 @@ class GradReducer:
         else:                                                     # gloo (CPU tests): SUM then divide
             self._handles.append((dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True), view))
 
+    def _realias(self, p, view):
+        """hook mode keeps ``param.grad`` a view of the flat buffer; ``optimizer.zero_grad(set_to_none=True)`` (the torch 2
+        default, and what mmcv's OptimizerHook calls every iteration) drops that view and autograd then allocates a
+        fresh gradient: move it into the buffer and re-point ``param.grad`` so the collective sees it."""
+        g = p.grad
+        if g is None:
+            view.zero_()
+        elif g.data_ptr() != view.data_ptr():
+            view.copy_(g)
+        p.grad = view
+
     def _on_grad(self, p):
+        if not self.pack:
+            self._realias(p, self._views[self._index[id(p)]])
         if not self.overlap:
             return
         b = self._bucket_of[p]
         self._pending[b] -= 1
-        if self._pending[b] == 0:
+        if self._pending[b] == 0 and self.world > 1:
             self._launch(b)
 
     def finish(self):
         """Call after backward (and after pack_grads() in pack mode): launches the buckets not launched from hooks,
         waits for all of them."""
+        if not self.pack:                 # parameters that got no gradient this step (or whose .grad was reset to None)
+            for p, v in zip(self._order, self._views):
+                if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                    if self._launched[self._bucket_of[p]]:
+                        raise RuntimeError("a gradient changed after its bucket was reduced")
+                    self._realias(p, v)
         if self.world > 1:
             for b in range(len(self.buckets)):
                 self._launch(b)
@@ -200,7 +242,11 @@ class BoundaryTap:
         self._hook.remove()
 
 
-def split_parameters(model, late_prefixes):
+def split_parameters(model, late_prefixes=None):
+    """(late, early) parameter lists: by name prefixes, or (None) the first group of ``model.grad_groups()`` vs the rest."""
+    if late_prefixes is None:
+        groups = model.grad_groups()
+        return list(groups[0]), [p for g in groups[1:] for p in g]
     late = [p for n, p in model.named_parameters() if n.startswith(tuple(late_prefixes))]
     early = [p for n, p in model.named_parameters() if not n.startswith(tuple(late_prefixes))]
     return late, early

@@ -32,6 +32,7 @@ class _ReduceQueue:
     # torch.utils.checkpoint segment is a pass of its own inside the outer one); each pass flushes its own jobs.
     #   "jobs": (src tensor, byte offset, dtype code, rows, cols, ld, dst tensor)
     #   "table_jobs": attention table gradients waiting for their binning launch (after the reductions)
+    #   "owners": data_ptr of every parameter that already has a postponed gradient in this pass
     tasks = {}
     slots = {}           # graph task id -> flat-gradient slots already handed out in that pass (grad_slot)
 
@@ -44,10 +45,13 @@ class _ReduceQueue:
 def set_deferred_reductions(on):
     """on=True: reductions whose result is a PARAMETER gradient (split-K partials of dW, bias-gradient partial rows,
     LayerNorm dgamma / dbeta rows) are queued while autograd runs and issued as one grouped launch when the backward pass
-    ends (an autograd engine callback), instead of ~120 launches of 5-8 us each.  The returned gradient tensors are
-    therefore filled only once backward() returns: use it when nothing reads ``param.grad`` earlier, i.e. no
-    post-accumulate hooks and no accumulation into existing ``.grad`` tensors (``zero_grad(set_to_none=True)`` or
-    dp.GradReducer(pack=True), which is what bench.py runs).  Returns the previous setting."""
+    ends (an autograd engine callback), instead of ~120 launches of 5-8 us each.  A postponed gradient tensor is filled
+    only once backward() returns, so a reduction is postponed only when nothing can read its result earlier: the
+    call site names the parameter(s) the result belongs to (``owners``), and the launch stays immediate when an owner
+    already holds a ``.grad`` (autograd would accumulate into it at once), carries a tensor / post-accumulate hook
+    (dp.GradReducer(pack=False) launches its all-reduce from one), or already received a postponed gradient in the same
+    pass (a module applied twice: autograd adds the two as soon as the second arrives; the queue is flushed first).
+    Returns the previous setting."""
     prev, _ReduceQueue.enabled = _ReduceQueue.enabled, bool(on)
     return prev
 
@@ -78,40 +82,58 @@ def _launch_table_grads(jobs, stages=3):
         call("pswin_attn_table_grads_batch", lst[0][0], ctypes.cast(arr, ctypes.c_void_p), len(lst), stages)
 
 
+def _launch_queue(q):
+    jobs, tjobs = q["jobs"], q["table_jobs"]
+    q["jobs"], q["table_jobs"] = [], []
+    if jobs:
+        _launch_reductions(jobs)
+    if tjobs:
+        _launch_table_grads(tjobs, 4)                   # per-bin sums from the partial-row sums the reductions just wrote
+
+
 def flush_reductions(task=None):
     """Issue the reductions queued by one backward pass (runs by itself when that pass ends); task=None: all of them."""
     keys = list(_ReduceQueue.tasks) if task is None else [task]
     for k in keys:
         q = _ReduceQueue.tasks.pop(k, None)
-        if q is None:
-            continue
-        if q["jobs"]:
-            _launch_reductions(q["jobs"])
-        if q["table_jobs"]:
-            _launch_table_grads(q["table_jobs"], 4)     # per-bin sums from the partial-row sums the reductions just wrote
+        if q is not None:
+            _launch_queue(q)
 
 
-def _deferring():
-    """The job queue of the running backward pass when deferred reductions are on (the end-of-pass callback is armed on
-    first use), else None."""
+def _has_hooks(p):
+    return bool(getattr(p, "_post_accumulate_grad_hooks", None)) or bool(getattr(p, "_backward_hooks", None))
+
+
+def _deferring(owners=()):
+    """The job queue of the running backward pass if the reduction that produces the gradients of `owners` (parameters)
+    may be postponed to the end of that pass (see set_deferred_reductions; the end-of-pass callback is armed on first
+    use), else None = launch now.  Without owners the destination is unknown and nothing is postponed."""
     task = torch._C._current_graph_task_id() if _ReduceQueue.enabled else -1
-    if task == -1:
+    owners = [o for o in owners if o is not None]
+    if task == -1 or not owners:
         return None
+    if any((not o.is_leaf) or o.grad is not None or _has_hooks(o) for o in owners):
+        return None                  # a non-leaf "owner" feeds further autograd nodes right away
     q = _ReduceQueue.tasks.get(task)
     if q is None:
-        q = _ReduceQueue.tasks[task] = {"jobs": [], "table_jobs": []}
+        q = _ReduceQueue.tasks[task] = {"jobs": [], "table_jobs": [], "owners": set()}
         _ReduceQueue.trim(_ReduceQueue.tasks)
         torch.autograd.Variable._execution_engine.queue_callback(lambda: flush_reductions(task))
+    keys = [o.data_ptr() for o in owners]
+    if any(k in q["owners"] for k in keys):
+        _launch_queue(q)             # second gradient of a parameter in one pass: autograd adds it to the first one now
+        return None
+    q["owners"].update(keys)
     return q
 
 
 def grad_slot(param):
     """The flat-gradient-buffer view dp.GradReducer(pack=True) reserved for `param` (``param._grad_slot``) if this backward
     pass may write the parameter's gradient straight into it: the parameter holds no gradient yet (nothing to accumulate
-    into) and the slot has not been handed out earlier in the same pass (a weight used twice gets a private buffer the
-    second time and autograd adds the two).  None otherwise."""
+    into), has no hooks, and the slot has not been handed out earlier in the same pass (a weight used twice gets a
+    private buffer the second time and autograd adds the two).  None otherwise."""
     slot = getattr(param, "_grad_slot", None)
-    if slot is None or param.grad is not None or slot.device != param.device:
+    if slot is None or not param.is_leaf or param.grad is not None or slot.device != param.device or _has_hooks(param):
         return None
     task = torch._C._current_graph_task_id()
     used = _ReduceQueue.slots.get(task)
@@ -124,9 +146,10 @@ def grad_slot(param):
     return slot
 
 
-def sum_rows(src, rows, cols, ld=None, col_offset=0, out=None):
+def sum_rows(src, rows, cols, ld=None, col_offset=0, out=None, owners=()):
     """f32 [cols]: out[c] = sum_{r < rows} src.flatten()[r * ld + col_offset + c] in a fixed order (pswin_reduce_jobs).
-    Inside a backward pass with set_deferred_reductions(True) the launch is postponed to the end of that pass.
+    owners: the parameters whose gradient the result is; inside a backward pass with set_deferred_reductions(True) the
+    launch is then postponed to the end of that pass when that is safe (_deferring).
     out: an existing contiguous f32 buffer of `cols` elements to write (see grad_slot); a fresh view of it is returned."""
     ld = cols if ld is None else ld
     if not src.is_contiguous():
@@ -135,7 +158,7 @@ def sum_rows(src, rows, cols, ld=None, col_offset=0, out=None):
         if out.dtype != torch.float32 or out.numel() != cols or not out.is_contiguous():
             raise PswinError("sum_rows: `out` must be a contiguous float32 buffer of `cols` elements")
         job = (src, col_offset * src.element_size(), dtype_code(src), rows, cols, ld, out)
-        q = _deferring()
+        q = _deferring(owners)
         if q is not None:
             q["jobs"].append(job)
         else:
@@ -143,7 +166,7 @@ def sum_rows(src, rows, cols, ld=None, col_offset=0, out=None):
         return out.view(cols)
     out = torch.empty(cols, dtype=torch.float32, device=src.device)
     job = (src, col_offset * src.element_size(), dtype_code(src), rows, cols, ld, out)
-    q = _deferring()
+    q = _deferring(owners)
     if q is None:
         _launch_reductions([job])
         return out
@@ -345,6 +368,7 @@ class _LayerNormGather(torch.autograd.Function):
         ctx.save_for_backward(x, gamma, mean, rstd, inv, res_scale)
         ctx.n_out = n_out
         ctx.want_res_sum = res_bias is not None
+        ctx.owners = (gamma, beta, res_bias)
         if passthrough:
             return y, x.view_as(x)
         return y
@@ -364,7 +388,7 @@ class _LayerNormGather(torch.autograd.Function):
         if dy is None:                                   # only the shortcut was used downstream
             if ctx.want_res_sum:
                 g = dres if res_scale is None else dres * res_scale[:, None, None]
-                dres_sum = colsum(g.reshape(-1, C))
+                dres_sum = colsum(g.reshape(-1, C), owners=ctx.owners[2:])
             return dres, torch.zeros_like(gamma), torch.zeros_like(gamma), None, None, None, None, None, dres_sum, None
         dy = dy.contiguous()
         lib = _lib.load()
@@ -374,7 +398,7 @@ class _LayerNormGather(torch.autograd.Function):
         call("pswin_ln_gather_bwd", x, ptr(dy), dtype_code(dy), ptr(inv), ptr(x), dtype_code(x), ptr(mean), ptr(rstd),
              ptr(gamma), ptr(dres), ptr(res_scale), ptr(dres) if ctx.want_res_sum else None, ptr(dx), None, None, ptr(ws),
              B, S, ctx.n_out, C, algo_bytes=B * S * C * (dy.element_size() + (2 if dres is None else 3) * x.element_size()))
-        sums = sum_rows(ws, lib.pswin_ln_partial_rows(B * S, C), nseg * C)
+        sums = sum_rows(ws, lib.pswin_ln_partial_rows(B * S, C), nseg * C, owners=ctx.owners)
         if ctx.want_res_sum:
             dres_sum = sums[2 * C:]
         return dx, sums[:C], sums[C:2 * C], None, None, None, None, None, dres_sum, None
@@ -416,6 +440,7 @@ class _ScatterAddLayerNorm(torch.autograd.Function):
              algo_bytes=B * S * C * (win.element_size() + 8 + y.element_size()))
         ctx.save_for_backward(x1, gamma, mean, rstd, wmap, scale, res_scale)
         ctx.win_dtype, ctx.want_res_sum = win.dtype, res_bias is not None
+        ctx.owners = (gamma, beta, res_bias)
         return y, x1
 
     @staticmethod
@@ -435,7 +460,7 @@ class _ScatterAddLayerNorm(torch.autograd.Function):
         call("pswin_ln_gather_bwd", x1, ptr(dy), dtype_code(dy), None, ptr(x1), dtype_code(x1), ptr(mean), ptr(rstd),
              ptr(gamma), ptr(dres), ptr(res_scale), ptr(dres) if ctx.want_res_sum else None, ptr(dx1), None, None, ptr(ws),
              B, S, S, C, algo_bytes=B * S * C * (dy.element_size() + (2 if dres is None else 3) * 4))
-        sums = sum_rows(ws, lib.pswin_ln_partial_rows(B * S, C), nseg * C)
+        sums = sum_rows(ws, lib.pswin_ln_partial_rows(B * S, C), nseg * C, owners=ctx.owners)
         dres_sum = sums[2 * C:] if ctx.want_res_sum else None
         dwin = _gather_raw(dx1, wmap, scale, wmap.numel(), ctx.win_dtype)          # window_scatter_add's backward
         return dwin, dx1, None, None, None, None, sums[:C], sums[C:2 * C], None, None, dres_sum, None
@@ -463,6 +488,7 @@ class _LayerNormNCHW(torch.autograd.Function):
         call("pswin_ln_nchw_fwd", x, ptr(x), ptr(gamma), ptr(beta), float(eps), ptr(y), ptr(mean), ptr(rstd), B, S, C,
              algo_bytes=2 * x.numel() * 4)
         ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.owners = (gamma, beta)
         if passthrough:
             return y, x.view_as(x)
         return y
@@ -481,7 +507,7 @@ class _LayerNormNCHW(torch.autograd.Function):
         ws = torch.empty(lib.pswin_ln_workspace(B * S, C), dtype=torch.float32, device=x.device)
         call("pswin_ln_nchw_bwd", x, ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(dres), ptr(dx), None, None,
              ptr(ws), B, S, C, algo_bytes=(3 if dres is None else 4) * x.numel() * 4)
-        sums = sum_rows(ws, lib.pswin_ln_partial_rows(B * S, C), 2 * C)
+        sums = sum_rows(ws, lib.pswin_ln_partial_rows(B * S, C), 2 * C, owners=ctx.owners)
         return dx, sums[:C], sums[C:], None, None, None, None
 
 
@@ -510,6 +536,7 @@ class _LayerNormPatchMerge(torch.autograd.Function):
         call("pswin_ln_patch_merge_fwd", x, ptr(x), dtype_code(x), ptr(gamma), ptr(beta), float(eps), ptr(y),
              dtype_code(y), ptr(mean), ptr(rstd), B, H, W, C)
         ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.owners = (gamma, beta)
         ctx.geom = (H, W)
         return y
 
@@ -525,7 +552,7 @@ class _LayerNormPatchMerge(torch.autograd.Function):
         ws = torch.empty(lib.pswin_ln_workspace(rows, 4 * C), dtype=torch.float32, device=x.device)
         call("pswin_ln_patch_merge_bwd", x, ptr(dy), dtype_code(dy), ptr(x), dtype_code(x), ptr(mean), ptr(rstd),
              ptr(gamma), ptr(dx), None, None, ptr(ws), B, H, W, C)
-        sums = sum_rows(ws, lib.pswin_ln_partial_rows(rows, 4 * C), 8 * C)
+        sums = sum_rows(ws, lib.pswin_ln_partial_rows(rows, 4 * C), 8 * C, owners=ctx.owners)
         return dx, sums[:4 * C], sums[4 * C:], None, None, None, None
 
 
@@ -584,20 +611,21 @@ def batch_norm_relu(y, bn, training, pre_bias=None):
                                 pre_bias)
 
 
-def colsum(x2d, zero_cols=None):
+def colsum(x2d, zero_cols=None, owners=()):
     """fp32 column sums of a [M, N] matrix (N % 8 == 0): bias gradients and split-K partial reductions.
-    zero_cols=(lo, hi): columns known to sum to zero (not read on the large-matrix path; see pswin_colsum_skip)."""
+    zero_cols=(lo, hi): columns known to sum to zero (not read on the large-matrix path; see pswin_colsum_skip).
+    owners: see sum_rows."""
     x2d = x2d.contiguous()
     M, N = x2d.shape
     if M <= 4096:
-        return sum_rows(x2d, M, N)
+        return sum_rows(x2d, M, N, owners=owners)
     n_ws = _lib.load().pswin_colsum_workspace(M, N, dtype_code(x2d))
     ws = torch.empty(n_ws, dtype=torch.float32, device=x2d.device)
     if zero_cols is None:
         call("pswin_colsum", x2d, ptr(x2d), dtype_code(x2d), M, N, None, ptr(ws))      # first stage: partial rows
     else:
         call("pswin_colsum_skip", x2d, ptr(x2d), dtype_code(x2d), M, N, int(zero_cols[0]), int(zero_cols[1]), ptr(ws))
-    return sum_rows(ws, n_ws // N, N)
+    return sum_rows(ws, n_ws // N, N, owners=owners)
 
 
 def skinny_gemm_supported(x2d, n_out):
@@ -635,7 +663,7 @@ class _Fc1Gelu(torch.autograd.Function):
         b = bias.detach().float().contiguous()
         call("pswin_fc1_gelu_fwd", x, ptr(x), ptr(wb), ptr(b), ptr(h), M, K, N, algo_bytes=2 * M * (K + N))
         ctx.save_for_backward(x, wb, b)
-        ctx.weight = weight
+        ctx.weight, ctx.bias = weight, bias
         return h
 
     @staticmethod
@@ -649,13 +677,13 @@ class _Fc1Gelu(torch.autograd.Function):
         ws = torch.empty(lib.pswin_fc1_gelu_workspace(N), dtype=torch.float32, device=x.device)
         call("pswin_fc1_gelu_bwd", x, ptr(x), ptr(wb), ptr(b), ptr(dh), ptr(dy), None, ptr(ws), M, K, N,
              algo_bytes=2 * M * (K + 2 * N))
-        db = sum_rows(ws, lib.pswin_fc1_gelu_partial_rows(M), N)
+        db = sum_rows(ws, lib.pswin_fc1_gelu_partial_rows(M), N, owners=(ctx.bias,))
         dx = skinny_gemm(dy, wb, None, transpose_w=True) if ctx.needs_input_grad[0] else None
         from .backbone import _pick_split
         ch = _pick_split(M, -(-N // 64) * -(-K // 64))
         if ch > 1:
             part = torch.bmm(dy.view(ch, M // ch, N).transpose(1, 2), x.view(ch, M // ch, K))
-            dw = sum_rows(part, ch, N * K, out=grad_slot(ctx.weight)).view(N, K)
+            dw = sum_rows(part, ch, N * K, out=grad_slot(ctx.weight), owners=(ctx.weight,)).view(N, K)
         else:
             dw = (dy.t() @ x).float()
         return dx, dw, db, None
@@ -679,6 +707,7 @@ class _BiasGelu(torch.autograd.Function):
         b = None if bias is None else bias.detach().float().contiguous()
         call("pswin_bias_gelu_fwd", y, ptr(y), dtype_code(y), ptr(b), ptr(h), M, N, algo_bytes=2 * y.numel() * y.element_size())
         ctx.save_for_backward(y, b)
+        ctx.bias = bias
         return h
 
     @staticmethod
@@ -691,7 +720,8 @@ class _BiasGelu(torch.autograd.Function):
         ws = torch.empty(lib.pswin_bias_gelu_workspace(M, N), dtype=torch.float32, device=y.device)
         call("pswin_bias_gelu_bwd", y, ptr(dh), ptr(y), dtype_code(y), ptr(b), ptr(dy), None, ptr(ws), M, N,
              algo_bytes=3 * y.numel() * y.element_size())
-        db = sum_rows(ws, lib.pswin_bias_gelu_partial_rows(M, N, dtype_code(y)), N) if b is not None else None
+        db = sum_rows(ws, lib.pswin_bias_gelu_partial_rows(M, N, dtype_code(y)), N, owners=(ctx.bias,)) \
+            if b is not None else None
         return dy, db
 
 
@@ -794,6 +824,7 @@ class _WindowAttention(torch.autograd.Function):
             assert x.dtype == k.dtype == v.dtype
             ld = C
             qp, kp, vp = x.data_ptr(), k.data_ptr(), v.data_ptr()
+        alpha_p, beta_p = (alpha if dist is not None else None), beta
         alpha = alpha.contiguous() if dist is not None else None
         beta = beta.contiguous()
         out = torch.empty(rows, C, dtype=x.dtype, device=x.device)
@@ -805,6 +836,7 @@ class _WindowAttention(torch.autograd.Function):
              algo_bytes=n * heads * 4 * WTOK * _lib.HEAD_DIM * x.element_size())
         ctx.fused, ctx.heads, ctx.scale, ctx.nb, ctx.n, ctx.C = fused, heads, float(scale), n_bias_windows, n, C
         ctx.dist, ctx.mask, ctx.chunks = dist, mask, chunks
+        ctx.owners = (alpha_p, beta_p)
         ctx.save_for_backward(x, k, v, lse, alpha, beta)
         return out
 
@@ -851,7 +883,7 @@ class _WindowAttention(torch.autograd.Function):
             _launch_table_grads([job], 1)
             ld = ws.numel() // 129
             rjob = (ws, 0, F32, lib.pswin_attn_table_grads_partial_rows(chunks * nb, heads), ld, ld, ws[128 * ld:])
-            q = _deferring()
+            q = _deferring(ctx.owners)
             if q is not None:
                 q["jobs"].append(rjob)
                 q["table_jobs"].append(job)

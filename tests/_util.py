@@ -12,6 +12,7 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TINY = dict(embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], ape=True, drop_path_rate=0.0)
 TINY_PITCH = dict(embed_dim=32, depths=[3, 2, 1, 2], num_heads=[1, 2, 4, 8], ape=True, drop_path_rate=0.0)
 TCFG = dict(embed_dim=96, depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24], ape=True, drop_path_rate=0.0)
+SCFG = dict(embed_dim=96, depths=[2, 2, 18, 2], num_heads=[3, 6, 12, 24], ape=True, drop_path_rate=0.0)
 
 # parameters whose true gradient is identically zero (a bias in front of BatchNorm; the key bias, to
 # which softmax is invariant): their computed gradients are rounding noise, compared with atol only.
@@ -68,11 +69,47 @@ def run_and_collect(m, shape, tag, device="cpu", subsample_out=None):
     return res
 
 
-def compare_to_golden(res, gold, rtol, atol, grad_rtol=None, grad_atol_frac=None, skip_noise=True):
-    """Outputs/dx: allclose(rtol, atol).  Param grads: |diff| <= grad_rtol*|ref| + grad_atol_frac*max|ref|."""
+REPORT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_report.json")
+
+
+def record(name, **values):
+    """Append measured worst-case errors to gpurun_out/parity_report.json (merged back from the GPU box): the numbers
+    the tolerances in the tests are set from.  Never affects a test's verdict."""
+    import json
+    try:
+        os.makedirs(os.path.dirname(REPORT), exist_ok=True)
+        data = {}
+        if os.path.exists(REPORT):
+            with open(REPORT) as f:
+                data = json.load(f)
+        data[name] = {k: (float(v) if isinstance(v, (int, float)) else v) for k, v in values.items()}
+        with open(REPORT, "w") as f:
+            json.dump(data, f, indent=1, sort_keys=True)
+    except (OSError, ValueError):
+        pass
+
+
+def rel_norm_errors(res, gold, prefixes=("grad:", "dx_sub")):
+    """{key: ||got - ref|| / ||ref||} over the stored (subsampled) vectors, keys with an exactly-zero true gradient
+    skipped.  This is the per-tensor bound used for the bf16 path: element-wise tolerances are meaningless for
+    gradients that are sums over 10^5 tokens of bf16-rounded products."""
+    out = {}
+    for k in gold.files:
+        if not k.startswith(prefixes) or any(z in k for z in ZERO_GRAD_KEYS):
+            continue
+        ref = torch.from_numpy(np.asarray(gold[k])).double()
+        got = res[k].double()
+        out[k] = float((got - ref).norm() / ref.norm().clamp_min(1e-30))
+    return out
+
+
+def compare_to_golden(res, gold, rtol, atol, grad_rtol=None, grad_atol_frac=None, skip_noise=True, report=None):
+    """Outputs/dx: allclose(rtol, atol).  Param grads: |diff| <= grad_rtol*|ref| + grad_atol_frac*max|ref|.
+    report: name under which the worst err/tol ratios (outputs, gradients) are recorded (see record)."""
     grad_rtol = rtol if grad_rtol is None else grad_rtol
     grad_atol_frac = 1e-5 if grad_atol_frac is None else grad_atol_frac
     bad = []
+    worst = {"out": (0.0, ""), "grad": (0.0, ""), "out_abs": (0.0, "")}
     for k in gold.files:
         if k.startswith(("gstep:", "out")) and k.endswith("_step") or k in ("dx_step", "dx_stats", "as_shimmed"):
             continue
@@ -94,7 +131,17 @@ def compare_to_golden(res, gold, rtol, atol, grad_rtol=None, grad_atol_frac=None
         else:
             tol = rtol * ref.abs() + atol
         err = (got - ref).abs()
+        kind = "grad" if k.startswith(("grad:", "gnorm:", "dx_sub")) else "out"
+        ratio = float((err / tol).max())
+        if ratio > worst[kind][0]:
+            worst[kind] = (ratio, k)
+        if kind == "out" and float(err.max()) > worst["out_abs"][0]:
+            worst["out_abs"] = (float(err.max()), k)
         if not bool((err <= tol).all()):
             i = int((err - tol).argmax())
             bad.append(f"{k}: max excess at {i}: got {got.reshape(-1)[i].item():.6g} ref {ref.reshape(-1)[i].item():.6g}")
+    if report:
+        record(report, out_err_over_tol=worst["out"][0], out_key=worst["out"][1], grad_err_over_tol=worst["grad"][0],
+               grad_key=worst["grad"][1], out_max_abs_err=worst["out_abs"][0], out_abs_key=worst["out_abs"][1],
+               rtol=rtol, atol=atol, grad_rtol=grad_rtol, grad_atol_frac=grad_atol_frac)
     assert not bad, "\n".join(bad[:20])

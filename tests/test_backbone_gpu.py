@@ -2,15 +2,16 @@
 import pytest
 import torch
 
-from _util import TCFG, TINY, TINY_PITCH, build_filled, compare_to_golden, golden, run_and_collect
+from _util import (SCFG, TCFG, TINY, TINY_PITCH, build_filled, compare_to_golden, golden, model_inputs, record,
+                   rel_norm_errors, run_and_collect, sub)
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _model(cfg, pano, tag, **kw):
+def _model(cfg, pano, tag, train=True, **kw):
     from panoswintransformerobjectdetection_amd import SimplePanoSwinTransformer
-    return build_filled(lambda **c: SimplePanoSwinTransformer(**c, **kw), cfg, pano, tag).to(DEV)
+    return build_filled(lambda **c: SimplePanoSwinTransformer(**c, **kw), cfg, pano, tag, train=train).to(DEV)
 
 
 @pytest.mark.parametrize("fixture,cfg,pano,shape,tag", [
@@ -29,22 +30,112 @@ def test_tiny_models_fp32(fixture, cfg, pano, shape, tag):
     compare_to_golden(res, golden(fixture), rtol=1e-4, atol=5e-4, grad_rtol=2e-3, grad_atol_frac=1e-3)
 
 
+@pytest.mark.parametrize("fixture,pano,shape", [("tiny_pano_eval", True, (2, 3, 64, 128)),
+                                                ("tiny_planar_eval", False, (2, 3, 60, 100))])
+def test_tiny_models_eval_mode_fp32(fixture, pano, shape):
+    """eval mode (BatchNorm running statistics, DropPath off; HOT:981-983): outputs, dx and every parameter gradient."""
+    m = _model(TINY, pano, "tiny", train=False)
+    assert not m.training
+    res = run_and_collect(m, shape, "tiny", device=DEV)
+    compare_to_golden(res, golden(fixture), rtol=1e-4, atol=5e-4, grad_rtol=2e-3, grad_atol_frac=1e-3, report=fixture)
+
+
 def test_T_512x1024_fp32():
+    """fp32 path at full PanoSwin-T size against the live reference's captured outputs / gradients.  SURVEY 8c states
+    atol 5e-4 on the LayerNorm-ed outputs; the measured worst error is recorded in gpurun_out/parity_report.json."""
     m = _model(TCFG, True, "T")
     res = run_and_collect(m, (2, 3, 512, 1024), "T", device=DEV, subsample_out=4096)
-    compare_to_golden(res, golden("T_512x1024_pano"), rtol=1e-3, atol=2e-3, grad_rtol=1e-2, grad_atol_frac=5e-3)
+    compare_to_golden(res, golden("T_512x1024_pano"), rtol=1e-4, atol=5e-4, grad_rtol=2e-3, grad_atol_frac=1e-3,
+                      report="T_512x1024_fp32")
 
 
-def test_T_512x1024_bf16_close_to_fp32():
-    """bf16 compute (bf16 GEMM/attention operands, fp32 accumulate + residual stream): outputs stay within 5e-2 of
-    the fp32 goldens on the unit-variance LayerNorm-ed maps."""
-    m = _model(TCFG, True, "T", compute_dtype=torch.bfloat16)
-    res = run_and_collect(m, (2, 3, 512, 1024), "T", device=DEV, subsample_out=4096)
-    g = golden("T_512x1024_pano")
+def _bf16_report(res, g, name, out_mean, out_max, rel_bound, gnorm_bound):
+    """bf16 path against the fp32 golden: outputs (mean / max abs error on the unit-variance LayerNorm-ed maps), and for
+    dx and EVERY parameter gradient the relative error of the stored subsample in the 2-norm plus the ratio of the full
+    gradient norms."""
+    worst_out = (0.0, 0.0)
     for i in range(4):
         ref = torch.from_numpy(g[f"out{i}_sub"])
         err = (res[f"out{i}_sub"] - ref).abs()
-        assert err.mean().item() < 2e-2 and err.max().item() < 0.25, (i, err.mean().item(), err.max().item())
+        worst_out = (max(worst_out[0], err.mean().item()), max(worst_out[1], err.max().item()))
+    rel = rel_norm_errors(res, g)
+    gn = {}
+    for k in g.files:
+        if k.startswith("gnorm:") and not any(z in k for z in ("proj.0.bias", "proj.3.bias", "k_linear.bias")):
+            gn[k] = abs(float(res[k]) / max(float(g[k]), 1e-30) - 1.0)
+    wk = max(rel, key=rel.get)
+    wg = max(gn, key=gn.get)
+    stem = {k: v for k, v in rel.items() if "patch_embed" in k}
+    record(name, out_mean_abs=worst_out[0], out_max_abs=worst_out[1], worst_rel=rel[wk], worst_rel_key=wk,
+           worst_gnorm_dev=gn[wg], worst_gnorm_key=wg, median_rel=sorted(rel.values())[len(rel) // 2],
+           worst_stem_rel=max(stem.values()) if stem else 0.0, n_keys=len(rel))
+    assert worst_out[0] < out_mean and worst_out[1] < out_max, worst_out
+    bad = {k: v for k, v in rel.items() if v > rel_bound}
+    assert not bad, sorted(bad.items(), key=lambda t: -t[1])[:10]
+    badn = {k: v for k, v in gn.items() if v > gnorm_bound}
+    assert not badn, sorted(badn.items(), key=lambda t: -t[1])[:10]
+    assert len(rel) > 150
+
+
+def test_T_512x1024_bf16_outputs_and_gradients():
+    """The benched precision (bf16 GEMM / attention / stem operands, fp32 accumulation, fp32 residual stream and master
+    weights) at full PanoSwin-T size against the fp32 golden of the live reference: outputs AND dx AND every parameter
+    gradient (fused stem, fused fc1+GELU recompute, bias gradients routed through the LayerNorm backward kernel).
+    Bounds = about 1.5x the measured worst case (gpurun_out/parity_report.json, key T_512x1024_bf16)."""
+    m = _model(TCFG, True, "T", compute_dtype=torch.bfloat16)
+    res = run_and_collect(m, (2, 3, 512, 1024), "T", device=DEV, subsample_out=4096)
+    _bf16_report(res, golden("T_512x1024_pano"), "T_512x1024_bf16", out_mean=2e-2, out_max=0.25, rel_bound=0.2,
+                 gnorm_bound=0.1)
+
+
+@pytest.mark.parametrize("cd", [torch.float32, torch.bfloat16])
+def test_T_512x1024_eval_forward(cd):
+    """BASELINE.json configs[0]: PanoSwin-T forward only, batch 2, 512x1024, eval mode (the fused stem's running-statistics
+    branch at full size in bf16)."""
+    m = _model(TCFG, True, "T", train=False, compute_dtype=cd)
+    g = golden("T_512x1024_pano_eval")
+    with torch.no_grad():
+        outs = m(model_inputs((2, 3, 512, 1024), "T").to(DEV))
+    worst_mean = worst_max = 0.0
+    for i, o in enumerate(outs):
+        err = (sub(o, 4096)[0].cpu() - torch.from_numpy(g[f"out{i}_sub"])).abs()
+        worst_mean, worst_max = max(worst_mean, err.mean().item()), max(worst_max, err.max().item())
+    record(f"T_512x1024_eval_{'fp32' if cd == torch.float32 else 'bf16'}", out_mean_abs=worst_mean, out_max_abs=worst_max)
+    if cd == torch.float32:
+        assert worst_max < 5e-4, worst_max
+    else:
+        assert worst_mean < 2e-2 and worst_max < 0.25, (worst_mean, worst_max)
+
+
+def test_S_1024x2048_fp32():
+    """BASELINE.json configs[4] geometry: PanoSwin-S (depths 2-2-18-2) on a 1024x2048 panorama, fp32, outputs + dx +
+    every parameter gradient against the live reference's capture."""
+    m = _model(SCFG, True, "S")
+    res = run_and_collect(m, (1, 3, 1024, 2048), "S", device=DEV, subsample_out=4096)
+    compare_to_golden(res, golden("S_1024x2048_pano"), rtol=1e-4, atol=5e-4, grad_rtol=2e-3, grad_atol_frac=1e-3,
+                      report="S_1024x2048_fp32")
+
+
+def test_S_1024x2048_bf16_outputs_and_gradients():
+    """configs[4] in its stated precision (bf16) against the fp32 golden."""
+    m = _model(SCFG, True, "S", compute_dtype=torch.bfloat16)
+    res = run_and_collect(m, (1, 3, 1024, 2048), "S", device=DEV, subsample_out=4096)
+    _bf16_report(res, golden("S_1024x2048_pano"), "S_1024x2048_bf16", out_mean=3e-2, out_max=0.4, rel_bound=0.3,
+                 gnorm_bound=0.15)
+
+
+def test_batch_8_equals_four_batches_of_2_in_eval_mode():
+    """The B = 8 workload of configs[1] is benched, the goldens hold B = 2: with BatchNorm in eval mode images are
+    independent, so one batch of 8 must equal four batches of 2 (fp32: same kernels per window, bit for bit except the
+    batch-looped attention items; bound 1e-5)."""
+    m = _model(TCFG, True, "T", train=False)
+    x = model_inputs((8, 3, 512, 1024), "B8").to(DEV)
+    with torch.no_grad():
+        full = m(x)
+        parts = [m(x[i:i + 2]) for i in range(0, 8, 2)]
+    for lvl in range(4):
+        cat = torch.cat([p[lvl] for p in parts], 0)
+        assert torch.allclose(full[lvl], cat, rtol=1e-5, atol=1e-5), lvl
 
 
 def test_interface_and_state_dict():
@@ -224,3 +315,49 @@ def test_two_piece_backward_equals_plain_backward():
     for k, p in m.named_parameters():
         assert p.grad is not None, k
         assert torch.allclose(p.grad, ref[k], rtol=1e-5, atol=1e-7 + 1e-5 * float(ref[k].abs().max())), k
+
+
+def test_deferred_reductions_stay_correct_when_a_result_is_read_before_the_pass_ends():
+    """ops.set_deferred_reductions(True) postpones a parameter-gradient reduction only when nothing can read it before
+    the pass ends.  Three cases that would otherwise add or clone unwritten memory: a Linear applied twice in one pass
+    (autograd adds the two gradients when the second arrives), accumulation into an existing .grad over two passes, and a
+    parameter with a post-accumulate hook (what dp.GradReducer(pack=False) registers)."""
+    from panoswintransformerobjectdetection_amd import ops
+    from panoswintransformerobjectdetection_amd.backbone import _linear
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(64, 64).to(DEV)
+    ln = torch.nn.LayerNorm(64).to(DEV)
+    x = torch.randn(2, 8192, 64, device=DEV)
+
+    def net():
+        h = ops.layer_norm_gather(x, ln.weight, ln.bias, ln.eps, out_dtype=torch.bfloat16)
+        h = _linear(h, lin, torch.bfloat16)
+        h = ops.layer_norm_gather(h.float(), ln.weight, ln.bias, ln.eps, out_dtype=torch.bfloat16)   # LayerNorm twice
+        return _linear(h, lin, torch.bfloat16).float().square().mean()                              # Linear twice
+
+    params = [lin.weight, lin.bias, ln.weight, ln.bias]
+
+    def run(passes, hook):
+        for p in params:
+            p.grad = None
+        seen = []
+        hs = [p.register_post_accumulate_grad_hook(lambda q: seen.append(q.grad.detach().clone())) for p in params] if hook else []
+        for _ in range(passes):
+            net().backward()
+        for h in hs:
+            h.remove()
+        return [p.grad.detach().clone() for p in params], seen
+
+    for passes, hook in ((1, False), (2, False), (1, True)):
+        prev = ops.set_deferred_reductions(False)
+        ref, ref_seen = run(passes, hook)
+        ops.set_deferred_reductions(True)
+        try:
+            got, got_seen = run(passes, hook)
+        finally:
+            ops.set_deferred_reductions(prev)
+        assert not ops._ReduceQueue.tasks
+        for a, b in zip(ref, got):
+            assert torch.isfinite(b).all() and torch.equal(a, b), (passes, hook)
+        for a, b in zip(ref_seen, got_seen):        # what a hook sees at accumulation time is already the final value
+            assert torch.equal(a, b), (passes, hook)

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 import panoswin_oracle as po
-from _util import TCFG, TINY, TINY_PITCH, build_filled, compare_to_golden, golden, run_and_collect
+from _util import SCFG, TCFG, TINY, TINY_PITCH, build_filled, compare_to_golden, golden, model_inputs, run_and_collect, sub
 from detfill import det_fill_module, det_uniform
 
 PANO_CASES = [(128, 256), (64, 128), (32, 64), (16, 32), (13, 25), (25, 49), (50, 99), (14, 28)]
@@ -126,6 +126,40 @@ def test_T_512x1024_forward_backward():
     m = build_filled(po.SimplePanoSwinTransformerOracle, TCFG, True, "T")
     res = run_and_collect(m, (2, 3, 512, 1024), "T", subsample_out=4096)
     compare_to_golden(res, golden("T_512x1024_pano"), rtol=1e-4, atol=1e-5, grad_rtol=1e-3, grad_atol_frac=1e-4)
+
+
+@pytest.mark.parametrize("fixture,pano,shape", [("tiny_pano_eval", True, (2, 3, 64, 128)),
+                                                ("tiny_planar_eval", False, (2, 3, 60, 100))])
+def test_tiny_models_eval_mode(fixture, pano, shape):
+    """eval mode (HOT:981-983 train(False)): BatchNorm running statistics, DropPath off; outputs + every gradient."""
+    m = build_filled(po.SimplePanoSwinTransformerOracle, TINY, pano, "tiny", train=False)
+    res = run_and_collect(m, shape, "tiny")
+    compare_to_golden(res, golden(fixture), rtol=1e-5, atol=1e-6, grad_rtol=1e-4, grad_atol_frac=1e-5)
+
+
+def test_T_512x1024_eval_forward():
+    """BASELINE.json configs[0]: PanoSwin-T forward only, batch 2, 512x1024, eval mode, against the live reference's
+    captured outputs."""
+    torch.set_num_threads(8)
+    m = build_filled(po.SimplePanoSwinTransformerOracle, TCFG, True, "T", train=False)
+    g = golden("T_512x1024_pano_eval")
+    with torch.no_grad():
+        outs = m(model_inputs((2, 3, 512, 1024), "T"))
+    for i, o in enumerate(outs):
+        ref = torch.from_numpy(g[f"out{i}_sub"])
+        assert torch.allclose(sub(o, 4096)[0], ref, rtol=1e-4, atol=1e-5), i
+
+
+def test_S_1024x2048_forward():
+    """BASELINE.json configs[4] geometry: PanoSwin-S (depths 2-2-18-2) on one 1024x2048 panorama, train-mode forward."""
+    torch.set_num_threads(8)
+    m = build_filled(po.SimplePanoSwinTransformerOracle, SCFG, True, "S")
+    g = golden("S_1024x2048_pano")
+    with torch.no_grad():
+        outs = m(model_inputs((1, 3, 1024, 2048), "S"))
+    for i, o in enumerate(outs):
+        ref = torch.from_numpy(g[f"out{i}_sub"])
+        assert torch.allclose(sub(o, 4096)[0], ref, rtol=1e-4, atol=2e-5), i
 
 
 def test_state_dict_keys_and_interface():

@@ -60,3 +60,28 @@ def test_reference_registry_name_and_kwargs():
     for k, p in ref_sig.parameters.items():
         if k not in ("self", "norm_layer"):
             assert p.default == ora_sig.parameters[k].default, k
+
+
+def test_product_class_matches_the_reference_interface():
+    """The PRODUCT class (not only the oracle): same constructor parameters and defaults as the live reference (HOT:781-801)
+    plus the single keyword ``compute_dtype``, and identical state-dict keys and shapes for pano / planar / pitch-block
+    configurations, so reference checkpoints load with strict=True.  Construction needs no GPU."""
+    import inspect
+    from panoswintransformerobjectdetection_amd import SimplePanoSwinTransformer
+    ns = ref_loader.load_reference()
+    ref_sig = inspect.signature(ns.SimplePanoSwinTransformer.__init__).parameters
+    got_sig = inspect.signature(SimplePanoSwinTransformer.__init__).parameters
+    assert list(got_sig) == list(ref_sig) + ["compute_dtype"]
+    for k, p in ref_sig.items():
+        if k not in ("self", "norm_layer"):
+            assert p.default == got_sig[k].default, k
+    for cfg in (TINY, TINY_PITCH, dict(TINY, ape=False, pano_mode=False), dict(TINY, out_indices=(1, 3)),
+                dict(embed_dim=96, depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24], ape=True)):
+        ref = ns.SimplePanoSwinTransformer(**cfg).state_dict()
+        got = SimplePanoSwinTransformer(**cfg).state_dict()
+        assert list(ref.keys()) == list(got.keys()), cfg
+        for k in ref:
+            assert ref[k].shape == got[k].shape and ref[k].dtype == got[k].dtype, k
+    # loading a reference state dict into the product is strict-clean
+    m = SimplePanoSwinTransformer(**TINY_PITCH)
+    m.load_state_dict(ns.SimplePanoSwinTransformer(**TINY_PITCH).state_dict(), strict=True)
