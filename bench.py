@@ -27,12 +27,26 @@ _MIOPEN_DB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "panoswint
 if os.path.isdir(_MIOPEN_DB):
     os.environ.setdefault("MIOPEN_USER_DB_PATH", _MIOPEN_DB)
 # hipBLASLt solution choice for the ~60 GEMM shapes of the step: results of a PyTorch TunableOp tuning run on MI355X
-# (one file per device ordinal, same content) are shipped and only READ here (tuning off): +5 % panoramas/s.
-_TUNABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "panoswintransformerobjectdetection_amd", "tunableop")
-if os.path.isfile(os.path.join(_TUNABLE, "tunableop_results0.csv")):
+# are shipped as one table and only READ here (tuning off): +5 % panoramas/s.
+_TUNABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "panoswintransformerobjectdetection_amd", "tunableop",
+                        "tunableop_results.csv")
+
+
+def use_shipped_gemm_table(table=_TUNABLE):
+    """TunableOp reads <name><device ordinal>.csv: give every ordinal of the node a copy of the ONE shipped table."""
+    if not os.path.isfile(table) or "PYTORCH_TUNABLEOP_FILENAME" in os.environ:
+        return
+    import shutil
+    import tempfile
+    d = tempfile.mkdtemp(prefix="pswin_tunableop_")
+    for ordinal in range(8):
+        shutil.copyfile(table, os.path.join(d, f"tunableop_results{ordinal}.csv"))
     os.environ.setdefault("PYTORCH_TUNABLEOP_ENABLED", "1")
     os.environ.setdefault("PYTORCH_TUNABLEOP_TUNING", "0")
-    os.environ.setdefault("PYTORCH_TUNABLEOP_FILENAME", os.path.join(_TUNABLE, "tunableop_results.csv"))
+    os.environ["PYTORCH_TUNABLEOP_FILENAME"] = os.path.join(d, "tunableop_results.csv")
+
+
+use_shipped_gemm_table()
 
 import torch
 import torch.distributed as dist
@@ -127,8 +141,8 @@ def main():
     # Synthetic objective: a fixed random linear functional of the four feature maps (what a detection head's
     # gradient looks like to the backbone: dense, zero-mean, O(1/numel)).  The mean of the LayerNorm-ed outputs used in
     # earlier rounds is ~0 with a degenerate gradient, and torch's two-pass global reductions of graph-pool tensors
-    # return stale values from the second hipGraph replay on (ROCm 7.0 / torch 2.10: tools/dbg_graph3.py); a dot
-    # product is a single-pass GEMV and replays bit-exactly (tools/dbg_graph6.py checks every gradient against eager).
+    # return stale values from the second hipGraph replay on (ROCm 7.0 / torch 2.10: tools/repro_graph_stale_reduction.py); a dot
+    # product is a single-pass GEMV and replays bit-exactly (tests/test_backbone_gpu.py::test_hipgraph_replay_matches_eager checks every gradient against eager).
     with torch.no_grad():
         loss_w = [torch.randn_like(o).flatten() / o.numel() for o in model(x)]
     for p in model.parameters():

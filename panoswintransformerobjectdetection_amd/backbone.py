@@ -360,7 +360,7 @@ class _ApeAdd(torch.autograd.Function):
     """x + Linear(feat)[None]  (the absolute position encoding, HOT:926-934: feat [S, 5] is input independent).
     Backward without a framework two-pass reduction: the bias gradient (a sum over all S tokens) goes through
     pswin_colsum.  torch's global reductions return stale results from the second replay of a captured hipGraph on this
-    stack (the semaphore memset node is not re-run: tools/dbg_graph3.py), which silently corrupted this one gradient."""
+    stack (the semaphore memset node is not re-run: tools/repro_graph_stale_reduction.py), which silently corrupted this one gradient."""
 
     @staticmethod
     def forward(ctx, x, feat, weight, bias):
