@@ -388,6 +388,24 @@ int pswin_attn_fwd(const void* q, const void* k, const void* v, int ld_qkv, cons
  * backward (backward = 1) kernel.  Returns the chunk count (>= 1) or PSWIN_ERR_ARG. */
 int pswin_attn_suggest_chunks(int n_windows, int n_bias_windows, int heads, int backward);
 
+/* The whole WindowAttention module per window in ONE kernel (HOT:274-323: self.qkv, the attention core above, self.proj):
+ *   y = softmax(scale * q k^T + bias) v @ Wproj^T   with [q | k | v] = x @ Wqkv^T + b_qkv,
+ * x: [n_windows*49, C] window rows (the output of pswin_ln_gather_fwd), y: [n_windows*49, C] WITHOUT the proj bias (the
+ * residual scatter kernel adds it, as on the unfused path).  The qkv tensor never exists in HBM: both weight matrices
+ * are resident in LDS as MFMA operand fragments and every product of a window runs out of registers
+ * (csrc/pswin_fused.hip).  w_qkv: [3C, C], w_proj: [C, C] (nn.Linear layout), b_qkv: f32 [3C] or NULL; dist / mask tiles,
+ * tables, n_bias_windows and scale as pswin_attn_fwd (forward tiles, not transposed).
+ * Training: pass qkv_out [n*49, 3C], att_out [n*49, C] (the attention output before proj) and lse_out f32 [n, heads, 64]
+ * (all three or none): exactly the tensors pswin_attn_bwd and the weight-gradient GEMMs of the unfused path read.
+ * Specialised for C = 96, heads = 3, PSWIN_BF16 (PanoSwin-T / -S stage 0); pswin_win_attn_fused_supported says so,
+ * anything else returns PSWIN_ERR_UNSUPPORTED.  Rounding points are those of the unfused bf16 path (qkv and the attention
+ * output rounded to bf16, f32 scores / softmax / accumulation). */
+int pswin_win_attn_fused_supported(int C, int heads, int dtype);
+int pswin_win_attn_fused_fwd(const void* x, const void* w_qkv, const float* b_qkv, const void* w_proj, const float* dist_tiles,
+                             int n_dist, const float* alpha, const float* beta, const float* mask_tiles, int n_mask, void* y,
+                             void* qkv_out, void* att_out, float* lse_out, long long n_windows, int n_bias_windows, int C,
+                             int heads, float scale, int dtype, void* stream);
+
 /* Gradients of pswin_attn_fwd.  dq, dk, dv use the q/k/v addressing (ld_dqkv), dout the out addressing.
  * dist_tiles_t / mask_tiles_t: the TRANSPOSED tiles.  n_chunks splits the batch loop (1 <= n_chunks <=
  * n_windows / n_bias_windows, must divide it).

@@ -79,6 +79,9 @@ _PROTOTYPES = {
     "pswin_interp_rows_adjoint": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "pswin_attn_pad_tiles": [_vp, _i, _i, _vp, _vp],
     "pswin_attn_fwd": [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _f, _i, _vp],
+    "pswin_win_attn_fused_supported": [_i, _i, _i],
+    "pswin_win_attn_fused_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _i,
+                                 _f, _i, _vp],
     "pswin_attn_suggest_chunks": [_i, _i, _i, _i],
     "pswin_attn_bwd": [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp,
                        _i, _i, _i, _i, _f, _i, _vp],
@@ -157,28 +160,49 @@ def stream_of(t):
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
-# Optional per-launch timing (bench.py): name -> list of (start_event, end_event, algorithmic_bytes).  The events
-# are recorded on the stream the kernel is launched on (torch's current stream), around that launch only.
+# Optional per-launch timing (bench.py): name -> list of (start_event, end_event, algorithmic_bytes, algorithmic_flops).
+# The events are recorded on the stream the kernel is launched on (torch's current stream), around that launch only.
 _TIMED = None
 
 
 def enable_timing(names):
-    """Start collecting HIP-event pairs around every launch of the named entry points."""
+    """Start collecting HIP-event pairs around every launch of the named entry points (and `timed` regions)."""
     global _TIMED
     _TIMED = {n: [] for n in names}
 
 
 def disable_timing():
-    """Stop collecting; returns {name: [(milliseconds, algorithmic_bytes), ...]} (synchronises)."""
+    """Stop collecting; returns {name: [(milliseconds, algorithmic_bytes, algorithmic_flops), ...]} (synchronises)."""
     global _TIMED
     rec, _TIMED = _TIMED, None
     if rec is None:
         return {}
     torch.cuda.synchronize()
-    return {n: [(s.elapsed_time(e), b) for s, e, b in lst] for n, lst in rec.items()}
+    return {n: [(s.elapsed_time(e), b, f) for s, e, b, f in lst] for n, lst in rec.items()}
 
 
-def call(name, ref_tensor, *args, algo_bytes=0):
+class timed:
+    """with timed("lib_gemm_fwd", bytes, flops): ...   -- the same event bracket for launches that do not go through
+    `call` (the library GEMMs issued through PyTorch).  Free when timing is off."""
+
+    def __init__(self, name, algo_bytes=0, algo_flops=0):
+        self.rec = _TIMED.get(name) if _TIMED is not None else None
+        self.b, self.f = algo_bytes, algo_flops
+
+    def __enter__(self):
+        if self.rec is not None:
+            self.s, self.e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.s.record()
+        return self
+
+    def __exit__(self, *exc):
+        if self.rec is not None:
+            self.e.record()
+            self.rec.append((self.s, self.e, self.b, self.f))
+        return False
+
+
+def call(name, ref_tensor, *args, algo_bytes=0, algo_flops=0):
     """Invoke an entry point on the current stream of ref_tensor's device and raise on a non-zero status."""
     lib = load()
     if not ref_tensor.is_cuda:
@@ -189,7 +213,7 @@ def call(name, ref_tensor, *args, algo_bytes=0):
             s.record()
             rc = getattr(lib, name)(*args, stream_of(ref_tensor))
             e.record()
-            _TIMED[name].append((s, e, algo_bytes))
+            _TIMED[name].append((s, e, algo_bytes, algo_flops))
         else:
             rc = getattr(lib, name)(*args, stream_of(ref_tensor))
     check(rc, name)

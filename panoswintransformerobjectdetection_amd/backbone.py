@@ -107,76 +107,7 @@ class WindowAttention(nn.Module, DoubleModeModule):
             self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
 
 
-def _pick_split(M, n_tiles):
-    """Number of K-splits for a weight-gradient GEMM with contraction length M and n_tiles output tiles: a divisor
-    of M that gives hipBLASLt about a thousand independent tiles while each split keeps >= 512 rows."""
-    want = max(1, min(M // 512, -(-1024 // n_tiles)))
-    best = 1
-    for c in range(1, min(M, 4 * want) + 1):
-        if M % c == 0 and abs(c - want) < abs(best - want):
-            best = c
-    return best
-
-
-class _LinearSplitK(torch.autograd.Function):
-    """y = x W^T + b with bf16 operands and fp32 master parameters.
-
-    Forward and dX are plain hipBLASLt GEMMs.  dW = dY^T X contracts over up to 275k window tokens into an output of
-    a few dozen tiles, which a single GEMM launch maps onto a few dozen workgroups (measured 470-535 us for the
-    stage-0 shapes on MI355X against a 20-50 us HBM floor); it is issued as a batched GEMM over row chunks (an
-    explicit split-K, 55-75 us) whose fp32 partial sum also removes the bf16 -> fp32 gradient cast."""
-
-    @staticmethod
-    def forward(ctx, x, weight, bias, w_lp, b_lp, zero_bias_cols=None):
-        # w_lp / b_lp: this step's bf16 copies of the fp32 master parameters (refreshed by ONE multi-tensor cast per
-        # forward, see SimplePanoSwinTransformer._refresh_lowp); gradients go to the fp32 masters.
-        wb = w_lp if w_lp is not None else weight.to(x.dtype)
-        ctx.save_for_backward(x, wb)
-        ctx.has_bias = bias is not None
-        ctx.zero_bias_cols = zero_bias_cols
-        ctx.weight, ctx.bias = weight, bias                 # for ops.grad_slot / owners: dW may be summed straight into its flat slot
-        if ops.skinny_gemm_supported(x, wb.shape[0]):       # stage-0 shapes: streaming HIP GEMM, weight resident in LDS
-            return ops.skinny_gemm(x, wb, bias)
-        bb = None if bias is None else (b_lp if b_lp is not None else bias.to(x.dtype))
-        return F.linear(x, wb, bb)
-
-    @staticmethod
-    def backward(ctx, dy):
-        x, wb = ctx.saved_tensors
-        dy = dy.contiguous()
-        M, N = dy.shape
-        K = x.shape[1]
-        dx = None
-        if ctx.needs_input_grad[0]:
-            # data gradient with the same kernel (weight transposed while it is staged) where that beats the library:
-            # the three stage-0 shapes with 96 output columns
-            if K == 96 and N in (96, 288, 384) and ops.skinny_gemm_supported(dy, K):
-                dx = ops.skinny_gemm(dy, wb, None, transpose_w=True)
-            else:
-                dx = dy @ wb
-        ch = _pick_split(M, -(-N // 64) * -(-K // 64))
-        if ch > 1:
-            part = torch.bmm(dy.view(ch, M // ch, N).transpose(1, 2), x.view(ch, M // ch, K))
-            dw = ops.sum_rows(part, ch, N * K, out=ops.grad_slot(ctx.weight), owners=(ctx.weight,)).view(N, K)
-        else:
-            dw = (dy.t() @ x).float()
-        db = ops.colsum(dy, ctx.zero_bias_cols, owners=(ctx.bias,)) if ctx.has_bias else None
-        return dx, dw, db, None, None, None
-
-
-def _linear(x, lin, cd, use_bias=True, zero_bias_cols=None):
-    """nn.Linear on rows.  fp32: F.linear (parity path).  bf16: split-K weight gradient, fp32 parameter gradients.
-    use_bias=False: the caller applies lin.bias itself (fused into the next row kernel).  zero_bias_cols=(lo, hi): output
-    columns whose gradient sums to zero over the rows (their bias gradient is zero; the column sum skips them)."""
-    if cd == torch.float32:
-        return F.linear(x.float(), lin.weight, lin.bias if use_bias else None)
-    shp = x.shape
-    x2 = x.to(cd).reshape(-1, shp[-1])
-    lp = lin.__dict__.get("_lowp")
-    w_lp, b_lp = lp if lp is not None else (None, None)
-    bias = lin.bias if use_bias else None
-    return _LinearSplitK.apply(x2, lin.weight, bias, w_lp, b_lp if use_bias else None,
-                               zero_bias_cols).view(*shp[:-1], lin.weight.shape[0])
+_pick_split, _LinearSplitK, _linear = ops._pick_split, ops._LinearSplitK, ops.linear     # (moved to ops.py; names kept)
 
 
 class PanoSwinTransformerBlock(nn.Module, DoubleModeModule):
@@ -220,10 +151,14 @@ class PanoSwinTransformerBlock(nn.Module, DoubleModeModule):
         win, x = ops.layer_norm_gather(x, n1.weight, n1.bias, n1.eps, wmap, inv, cd, passthrough=True,
                                        res_bias=a.proj.bias if fuse else None, res_scale=s1)   # [B, nW*49, C]
         # the K third of d(qkv) sums to zero over every window (rows of dS sum to 0): its bias gradient is not summed
-        qkv = _linear(win.view(-1, C), a.qkv, cd, zero_bias_cols=(C, 2 * C))      # [B*nW*49, 3C]
-        att = ops.window_attention(qkv, a.sphere_position_alpha_table_Te, a.sphere_position_beta_table_Te, dist, mask,
-                                   a.num_heads, a.scale, nW)
-        att = _linear(att, a.proj, cd, use_bias=not fuse).view(B, nW * WTOK, C)
+        if fuse and ops.FUSED_WINDOW_ATTENTION and ops.window_attention_fused_supported(win.view(-1, C), a.num_heads):
+            # C = 96: qkv Linear, attention and proj Linear of a window in one kernel, weights resident in LDS
+            att = ops.window_attention_fused(win.view(-1, C), a, dist, mask, nW).view(B, nW * WTOK, C)
+        else:
+            qkv = _linear(win.view(-1, C), a.qkv, cd, zero_bias_cols=(C, 2 * C))      # [B*nW*49, 3C]
+            att = ops.window_attention(qkv, a.sphere_position_alpha_table_Te, a.sphere_position_beta_table_Te, dist, mask,
+                                       a.num_heads, a.scale, nW)
+            att = _linear(att, a.proj, cd, use_bias=not fuse).view(B, nW * WTOK, C)
         n2 = self.norm2
         if x.dtype == torch.float32 and C <= 1024:
             # shortcut + DropPath(attn) and norm2 of the sum in one kernel (the sum is not read back by a LayerNorm pass)

@@ -5,13 +5,17 @@ There is no PyTorch/CPU fallback: a CPU tensor or a missing library raises ``Psw
 Reference file:line citations use HOT = mmdet/models/backbones/simple_panoswin_transformer.py.
 """
 import math
+import os
 
 import torch
+import torch.nn.functional as F
 
 from . import _lib
 from ._lib import BF16, F32, MODE_PANO, MODE_PLANAR, WPAD, WTOK, PswinError, call, dtype_code, ptr
 
 _CACHE = {}
+# the per-window qkv -> attention -> proj kernel where it exists (C = 96); PSWIN_FUSED_ATTN=0 selects the unfused chain (A/B)
+FUSED_WINDOW_ATTENTION = os.environ.get("PSWIN_FUSED_ATTN", "1") != "0"
 
 
 def _dev_key(device):
@@ -648,6 +652,91 @@ def skinny_gemm(x2d, w, bias=None, transpose_w=False):
     return y
 
 
+def _pick_split(M, n_tiles):
+    """Number of K-splits for a weight-gradient GEMM with contraction length M and n_tiles output tiles: a divisor
+    of M that gives hipBLASLt about a thousand independent tiles while each split keeps >= 512 rows."""
+    want = max(1, min(M // 512, -(-1024 // n_tiles)))
+    best = 1
+    for c in range(1, min(M, 4 * want) + 1):
+        if M % c == 0 and abs(c - want) < abs(best - want):
+            best = c
+    return best
+
+
+class _LinearSplitK(torch.autograd.Function):
+    """y = x W^T + b with bf16 operands and fp32 master parameters.
+
+    Forward and dX are plain hipBLASLt GEMMs.  dW = dY^T X contracts over up to 275k window tokens into an output of
+    a few dozen tiles, which a single GEMM launch maps onto a few dozen workgroups (measured 470-535 us for the
+    stage-0 shapes on MI355X against a 20-50 us HBM floor); it is issued as a batched GEMM over row chunks (an
+    explicit split-K, 55-75 us) whose fp32 partial sum also removes the bf16 -> fp32 gradient cast."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, w_lp, b_lp, zero_bias_cols=None):
+        # w_lp / b_lp: this step's bf16 copies of the fp32 master parameters (refreshed by ONE multi-tensor cast per
+        # forward, see SimplePanoSwinTransformer._refresh_lowp); gradients go to the fp32 masters.
+        wb = w_lp if w_lp is not None else weight.to(x.dtype)
+        ctx.save_for_backward(x, wb)
+        ctx.has_bias = bias is not None
+        ctx.zero_bias_cols = zero_bias_cols
+        ctx.weight, ctx.bias = weight, bias                 # for grad_slot / owners: dW may be summed straight into its flat slot
+        if skinny_gemm_supported(x, wb.shape[0]):       # stage-0 shapes: streaming HIP GEMM, weight resident in LDS
+            return skinny_gemm(x, wb, bias)
+        bb = None if bias is None else (b_lp if b_lp is not None else bias.to(x.dtype))
+        M, K, N = x.shape[0], x.shape[1], wb.shape[0]
+        with _lib.timed("lib_gemm_fwd", 2 * (M * K + M * N + N * K), 2 * M * K * N):
+            return F.linear(x, wb, bb)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wb = ctx.saved_tensors
+        dx, dw, db = linear_backward(x, wb, dy, ctx.weight, ctx.bias if ctx.has_bias else None, ctx.zero_bias_cols,
+                                     ctx.needs_input_grad[0])
+        return dx, dw, db, None, None, None
+
+
+def linear_backward(x, wb, dy, weight, bias, zero_bias_cols, need_dx):
+    """Gradients of y = x wb^T (+ bias) for bf16 rows x [M, K], wb [N, K]: (dx or None, dW f32 [N, K], dbias f32 [N] or
+    None).  weight / bias: the fp32 master parameters the gradients belong to (grad_slot / deferred reductions)."""
+    dy = dy.contiguous()
+    M, N = dy.shape
+    K = x.shape[1]
+    dx = None
+    if need_dx:
+        # data gradient with the streaming kernel (weight transposed while it is staged) where that beats the library:
+        # the three stage-0 shapes with 96 output columns
+        if K == 96 and N in (96, 288, 384) and skinny_gemm_supported(dy, K):
+            dx = skinny_gemm(dy, wb, None, transpose_w=True)
+        else:
+            with _lib.timed("lib_gemm_dgrad", 2 * (M * K + M * N + N * K), 2 * M * K * N):
+                dx = dy @ wb
+    ch = _pick_split(M, -(-N // 64) * -(-K // 64))
+    with _lib.timed("lib_gemm_wgrad", 2 * (M * K + M * N) + 4 * N * K, 2 * M * K * N):
+        if ch > 1:
+            part = torch.bmm(dy.view(ch, M // ch, N).transpose(1, 2), x.view(ch, M // ch, K))
+        else:
+            dw = (dy.t() @ x).float()
+    if ch > 1:
+        dw = sum_rows(part, ch, N * K, out=grad_slot(weight), owners=(weight,)).view(N, K)
+    db = colsum(dy, zero_bias_cols, owners=(bias,)) if bias is not None else None
+    return dx, dw, db
+
+
+def linear(x, lin, cd, use_bias=True, zero_bias_cols=None):
+    """nn.Linear on rows.  fp32: F.linear (parity path).  bf16: split-K weight gradient, fp32 parameter gradients.
+    use_bias=False: the caller applies lin.bias itself (fused into the next row kernel).  zero_bias_cols=(lo, hi): output
+    columns whose gradient sums to zero over the rows (their bias gradient is zero; the column sum skips them)."""
+    if cd == torch.float32:
+        return F.linear(x.float(), lin.weight, lin.bias if use_bias else None)
+    shp = x.shape
+    x2 = x.to(cd).reshape(-1, shp[-1])
+    lp = lin.__dict__.get("_lowp")
+    w_lp, b_lp = lp if lp is not None else (None, None)
+    bias = lin.bias if use_bias else None
+    return _LinearSplitK.apply(x2, lin.weight, bias, w_lp, b_lp if use_bias else None,
+                               zero_bias_cols).view(*shp[:-1], lin.weight.shape[0])
+
+
 class _Fc1Gelu(torch.autograd.Function):
     """h = gelu(x W1^T + b1) for the stage-0 Mlp in ONE streaming pass (pswin_fc1_gelu_fwd); the backward pass recomputes
     the pre-activation (K = 96) instead of storing it: dy = dh gelu'(.), db1 = column sums of dy, dx = dy W1 (streaming
@@ -679,13 +768,14 @@ class _Fc1Gelu(torch.autograd.Function):
              algo_bytes=2 * M * (K + 2 * N))
         db = sum_rows(ws, lib.pswin_fc1_gelu_partial_rows(M), N, owners=(ctx.bias,))
         dx = skinny_gemm(dy, wb, None, transpose_w=True) if ctx.needs_input_grad[0] else None
-        from .backbone import _pick_split
         ch = _pick_split(M, -(-N // 64) * -(-K // 64))
+        with _lib.timed("lib_gemm_wgrad", 2 * (M * K + M * N) + 4 * N * K, 2 * M * K * N):
+            if ch > 1:
+                part = torch.bmm(dy.view(ch, M // ch, N).transpose(1, 2), x.view(ch, M // ch, K))
+            else:
+                dw = (dy.t() @ x).float()
         if ch > 1:
-            part = torch.bmm(dy.view(ch, M // ch, N).transpose(1, 2), x.view(ch, M // ch, K))
             dw = sum_rows(part, ch, N * K, out=grad_slot(ctx.weight), owners=(ctx.weight,)).view(N, K)
-        else:
-            dw = (dy.t() @ x).float()
         return dx, dw, db, None
 
 
@@ -842,57 +932,66 @@ class _WindowAttention(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        import ctypes
         x, k, v, lse, alpha, beta = ctx.saved_tensors
-        heads, n, nb, C = ctx.heads, ctx.n, ctx.nb, ctx.C
-        dist, mask = ctx.dist, ctx.mask
-        dout = dout.contiguous()
-        es = x.element_size()
-        if ctx.fused:
-            dx = torch.empty_like(x)
-            ld = 3 * C
-            qp, kp, vp = x.data_ptr(), x.data_ptr() + C * es, x.data_ptr() + 2 * C * es
-            dqp, dkp, dvp = dx.data_ptr(), dx.data_ptr() + C * es, dx.data_ptr() + 2 * C * es
-            dk = dv = None
-        else:
-            dx, dk, dv = torch.empty_like(x), torch.empty_like(k), torch.empty_like(v)
-            ld = C
-            qp, kp, vp = x.data_ptr(), k.data_ptr(), v.data_ptr()
-            dqp, dkp, dvp = dx.data_ptr(), dk.data_ptr(), dv.data_ptr()
-        need_tables = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
-        lib = _lib.load()
-        chunks = ctx.chunks or lib.pswin_attn_suggest_chunks(n, nb, heads, 1)
-        dalpha = dbeta = gsum = None
-        if need_tables:
-            gsum = torch.empty(chunks * nb, heads, WPAD, WPAD, dtype=torch.float32, device=x.device)
-        call("pswin_attn_bwd", x, ctypes.c_void_p(qp), ctypes.c_void_p(kp), ctypes.c_void_p(vp), ld,
-             ptr(None if dist is None else dist.bwd), 0 if dist is None else dist.n, ptr(alpha), ptr(beta),
-             ptr(None if mask is None else mask.bwd), 0 if mask is None else mask.n, ptr(dout), C, ptr(lse),
-             ctypes.c_void_p(dqp), ctypes.c_void_p(dkp), ctypes.c_void_p(dvp), ld, ptr(gsum),
-             chunks, n, nb, heads, ctx.scale, dtype_code(x),
-             algo_bytes=n * heads * 7 * WTOK * _lib.HEAD_DIM * x.element_size())
-        if need_tables:
-            dbeta = torch.empty(169, heads, dtype=torch.float32, device=x.device)
-            dalpha = torch.empty_like(dbeta) if dist is not None else None
-            ws = torch.empty(lib.pswin_attn_table_grads_workspace(heads), dtype=torch.float32, device=x.device)
-            job = (gsum, None if dist is None else dist.bwd, dalpha, dbeta, ws, chunks * nb, nb,
-                   0 if dist is None else dist.n, heads)
-            # the sum over the dScore tiles runs now (they are still in the last-level cache); with deferred reductions
-            # the sum of its partial rows joins the grouped launch at the end of the pass and ONE binning launch serves
-            # all attention modules (same kernels, same order either way: bitwise equal results)
-            _launch_table_grads([job], 1)
-            ld = ws.numel() // 129
-            rjob = (ws, 0, F32, lib.pswin_attn_table_grads_partial_rows(chunks * nb, heads), ld, ld, ws[128 * ld:])
-            q = _deferring(ctx.owners)
-            if q is not None:
-                q["jobs"].append(rjob)
-                q["table_jobs"].append(job)
-                dbeta = dbeta.view(169, heads)                       # fresh views: see sum_rows
-                dalpha = None if dalpha is None else dalpha.view(169, heads)
-            else:
-                _launch_reductions([rjob])
-                _launch_table_grads([job], 4)
+        dx, dk, dv, dalpha, dbeta = attention_backward(x, k, v, lse, alpha, beta, ctx.dist, ctx.mask, dout, ctx.heads, ctx.scale,
+                                                       ctx.nb, ctx.chunks, ctx.needs_input_grad[3] or ctx.needs_input_grad[4],
+                                                       ctx.owners)
         return dx, dk, dv, dalpha, dbeta, None, None, None, None, None, None
+
+
+def attention_backward(x, k, v, lse, alpha, beta, dist, mask, dout, heads, scale, nb, chunks, need_tables, owners):
+    """Backward of the attention core (pswin_attn_bwd + the table-gradient kernels): x = fused [rows, 3C] qkv (k = v =
+    None) or q with separate k, v.  Returns (dx, dk, dv, dalpha, dbeta); owners = the (alpha, beta) parameters."""
+    import ctypes
+    C = heads * _lib.HEAD_DIM
+    n = x.shape[0] // WTOK
+    fused = k is None
+    dout = dout.contiguous()
+    es = x.element_size()
+    if fused:
+        dx = torch.empty_like(x)
+        ld = 3 * C
+        qp, kp, vp = x.data_ptr(), x.data_ptr() + C * es, x.data_ptr() + 2 * C * es
+        dqp, dkp, dvp = dx.data_ptr(), dx.data_ptr() + C * es, dx.data_ptr() + 2 * C * es
+        dk = dv = None
+    else:
+        dx, dk, dv = torch.empty_like(x), torch.empty_like(k), torch.empty_like(v)
+        ld = C
+        qp, kp, vp = x.data_ptr(), k.data_ptr(), v.data_ptr()
+        dqp, dkp, dvp = dx.data_ptr(), dk.data_ptr(), dv.data_ptr()
+    lib = _lib.load()
+    chunks = chunks or lib.pswin_attn_suggest_chunks(n, nb, heads, 1)
+    dalpha = dbeta = gsum = None
+    if need_tables:
+        gsum = torch.empty(chunks * nb, heads, WPAD, WPAD, dtype=torch.float32, device=x.device)
+    call("pswin_attn_bwd", x, ctypes.c_void_p(qp), ctypes.c_void_p(kp), ctypes.c_void_p(vp), ld,
+         ptr(None if dist is None else dist.bwd), 0 if dist is None else dist.n, ptr(alpha), ptr(beta),
+         ptr(None if mask is None else mask.bwd), 0 if mask is None else mask.n, ptr(dout), C, ptr(lse),
+         ctypes.c_void_p(dqp), ctypes.c_void_p(dkp), ctypes.c_void_p(dvp), ld, ptr(gsum),
+         chunks, n, nb, heads, scale, dtype_code(x),
+         algo_bytes=n * heads * 7 * WTOK * _lib.HEAD_DIM * x.element_size())
+    if need_tables:
+        dbeta = torch.empty(169, heads, dtype=torch.float32, device=x.device)
+        dalpha = torch.empty_like(dbeta) if dist is not None else None
+        ws = torch.empty(lib.pswin_attn_table_grads_workspace(heads), dtype=torch.float32, device=x.device)
+        job = (gsum, None if dist is None else dist.bwd, dalpha, dbeta, ws, chunks * nb, nb,
+               0 if dist is None else dist.n, heads)
+        # the sum over the dScore tiles runs now (they are still in the last-level cache); with deferred reductions
+        # the sum of its partial rows joins the grouped launch at the end of the pass and ONE binning launch serves
+        # all attention modules (same kernels, same order either way: bitwise equal results)
+        _launch_table_grads([job], 1)
+        ld = ws.numel() // 129
+        rjob = (ws, 0, F32, lib.pswin_attn_table_grads_partial_rows(chunks * nb, heads), ld, ld, ws[128 * ld:])
+        q = _deferring(owners)
+        if q is not None:
+            q["jobs"].append(rjob)
+            q["table_jobs"].append(job)
+            dbeta = dbeta.view(169, heads)                       # fresh views: see sum_rows
+            dalpha = None if dalpha is None else dalpha.view(169, heads)
+        else:
+            _launch_reductions([rjob])
+            _launch_table_grads([job], 4)
+    return dx, dk, dv, dalpha, dbeta
 
 
 def window_attention(qkv, alpha, beta, dist, mask, heads, scale, n_bias_windows, k=None, v=None, chunks=None):
@@ -905,3 +1004,70 @@ def window_attention(qkv, alpha, beta, dist, mask, heads, scale, n_bias_windows,
     """
     return _WindowAttention.apply(qkv, k, v, alpha, beta, _as_tiles(dist), _as_tiles(mask), heads, scale,
                                   n_bias_windows, chunks)
+
+
+class _WindowAttentionFused(torch.autograd.Function):
+    """WindowAttention.forward (HOT:274-323) as ONE kernel per direction-of-use: qkv Linear, attention core and proj Linear
+    of a window run out of registers (pswin_win_attn_fused_fwd); the qkv tensor is written only when a backward pass
+    will read it.  The backward pass is the unfused chain on the saved tensors (proj gradients, pswin_attn_bwd, qkv
+    gradients): identical kernels and summation order to the unfused path."""
+
+    @staticmethod
+    def forward(ctx, x, w_qkv, b_qkv, w_proj, alpha, beta, dist, mask, heads, scale, n_bias_windows, wq_lp, wp_lp, grad_mode):
+        x = x.contiguous()
+        rows, C = x.shape
+        n = rows // WTOK
+        assert rows % WTOK == 0 and C == heads * _lib.HEAD_DIM
+        wq = (wq_lp if wq_lp is not None else w_qkv.to(x.dtype)).contiguous()
+        wp = (wp_lp if wp_lp is not None else w_proj.to(x.dtype)).contiguous()
+        bq = None if b_qkv is None else b_qkv.detach().float().contiguous()
+        alpha_c = alpha.detach().contiguous() if dist is not None else None
+        beta_c = beta.detach().contiguous()
+        # grad_mode = torch.is_grad_enabled() of the CALLER (inside forward() it is always off, and needs_input_grad
+        # ignores torch.no_grad()): without a backward pass to come, qkv / the attention output / lse are never written
+        save = grad_mode and any(ctx.needs_input_grad)
+        y = torch.empty_like(x)
+        qkv = att = lse = None
+        if save:
+            qkv = torch.empty(rows, 3 * C, dtype=x.dtype, device=x.device)
+            att = torch.empty_like(x)
+            lse = torch.empty(n, heads, WPAD, dtype=torch.float32, device=x.device)
+        flops = n * (2 * WTOK * C * 3 * C + heads * 4 * WTOK * WTOK * _lib.HEAD_DIM + 2 * WTOK * C * C)
+        call("pswin_win_attn_fused_fwd", x, ptr(x), ptr(wq), ptr(bq), ptr(wp), ptr(None if dist is None else dist.fwd),
+             0 if dist is None else dist.n, ptr(alpha_c), ptr(beta_c), ptr(None if mask is None else mask.fwd),
+             0 if mask is None else mask.n, ptr(y), ptr(qkv), ptr(att), ptr(lse), n, n_bias_windows, C, heads, float(scale),
+             dtype_code(x), algo_bytes=rows * C * 2 * (6 if save else 2), algo_flops=flops)
+        if save:
+            ctx.save_for_backward(x, qkv, att, lse, wq, wp, alpha_c, beta_c)
+            ctx.params = (w_qkv, b_qkv, w_proj, alpha if dist is not None else None, beta)
+            ctx.cfg = (dist, mask, heads, float(scale), n_bias_windows)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, qkv, att, lse, wq, wp, alpha_c, beta_c = ctx.saved_tensors
+        w_qkv, b_qkv, w_proj, alpha, beta = ctx.params
+        dist, mask, heads, scale, nb = ctx.cfg
+        C = x.shape[1]
+        datt, dwp, _ = linear_backward(att, wp, dy, w_proj, None, None, True)
+        dqkv, _, _, dalpha, dbeta = attention_backward(qkv, None, None, lse, alpha_c, beta_c, dist, mask, datt, heads, scale, nb,
+                                                        None, ctx.needs_input_grad[4] or ctx.needs_input_grad[5], (alpha, beta))
+        # the K third of d(qkv) sums to zero over every window (rows of dS sum to 0): its bias gradient is not summed
+        dx, dwq, dbq = linear_backward(x, wq, dqkv, w_qkv, b_qkv, (C, 2 * C), ctx.needs_input_grad[0])
+        return dx, dwq, dbq, dwp, dalpha, dbeta, None, None, None, None, None, None, None, None
+
+
+def window_attention_fused_supported(x2d, heads):
+    return (x2d.is_cuda and x2d.dim() == 2 and x2d.dtype == torch.bfloat16
+            and bool(_lib.load().pswin_win_attn_fused_supported(x2d.shape[1], heads, BF16)))
+
+
+def window_attention_fused(x2d, attn, dist, mask, n_bias_windows):
+    """proj(attention(qkv(x2d))) WITHOUT the proj bias for window rows x2d [n*49, C] and the parameter holder `attn`
+    (qkv, proj, the two tables, num_heads, scale): see _WindowAttentionFused."""
+    lq, lp = attn.qkv.__dict__.get("_lowp"), attn.proj.__dict__.get("_lowp")
+    return _WindowAttentionFused.apply(x2d, attn.qkv.weight, attn.qkv.bias, attn.proj.weight,
+                                       attn.sphere_position_alpha_table_Te, attn.sphere_position_beta_table_Te,
+                                       _as_tiles(dist), _as_tiles(mask), attn.num_heads, attn.scale, n_bias_windows,
+                                       lq[0] if lq is not None else None, lp[0] if lp is not None else None,
+                                       torch.is_grad_enabled())

@@ -45,11 +45,14 @@ def test_T_512x1024_fp32():
     atol 5e-4 on the LayerNorm-ed outputs; the measured worst error is recorded in gpurun_out/parity_report.json."""
     m = _model(TCFG, True, "T")
     res = run_and_collect(m, (2, 3, 512, 1024), "T", device=DEV, subsample_out=4096)
+    # measured (gpurun_out/parity_report.json): outputs max |err| 5.5e-6; parameter gradients 0.26 of (2e-3, 1e-3); the input
+    # gradient (through the two train-mode BatchNorms of the MIOpen fp32 stem) 3e-4 in relative 2-norm with isolated
+    # near-cancellation elements at 2.9x that pair, hence its own (1e-2, 5e-3)
     compare_to_golden(res, golden("T_512x1024_pano"), rtol=1e-4, atol=5e-4, grad_rtol=2e-3, grad_atol_frac=1e-3,
-                      report="T_512x1024_fp32")
+                      dx_tol=(1e-2, 5e-3), report="T_512x1024_fp32")
 
 
-def _bf16_report(res, g, name, out_mean, out_max, rel_bound, gnorm_bound):
+def _bf16_report(res, g, name, out_mean, out_max, rel_bound, gnorm_bound, nonstem_rel_bound=None):
     """bf16 path against the fp32 golden: outputs (mean / max abs error on the unit-variance LayerNorm-ed maps), and for
     dx and EVERY parameter gradient the relative error of the stored subsample in the 2-norm plus the ratio of the full
     gradient norms."""
@@ -66,12 +69,18 @@ def _bf16_report(res, g, name, out_mean, out_max, rel_bound, gnorm_bound):
     wk = max(rel, key=rel.get)
     wg = max(gn, key=gn.get)
     stem = {k: v for k, v in rel.items() if "patch_embed" in k}
+    rest = {k: v for k, v in rel.items() if "patch_embed" not in k}
+    wr = max(rest, key=rest.get)
     record(name, out_mean_abs=worst_out[0], out_max_abs=worst_out[1], worst_rel=rel[wk], worst_rel_key=wk,
+           worst_nonstem_rel=rest[wr], worst_nonstem_key=wr,
            worst_gnorm_dev=gn[wg], worst_gnorm_key=wg, median_rel=sorted(rel.values())[len(rel) // 2],
            worst_stem_rel=max(stem.values()) if stem else 0.0, n_keys=len(rel))
     assert worst_out[0] < out_mean and worst_out[1] < out_max, worst_out
     bad = {k: v for k, v in rel.items() if v > rel_bound}
     assert not bad, sorted(bad.items(), key=lambda t: -t[1])[:10]
+    if nonstem_rel_bound is not None:             # everything behind the stem (attention, MLP, norms, merging, tables)
+        bad = {k: v for k, v in rest.items() if v > nonstem_rel_bound}
+        assert not bad, sorted(bad.items(), key=lambda t: -t[1])[:10]
     badn = {k: v for k, v in gn.items() if v > gnorm_bound}
     assert not badn, sorted(badn.items(), key=lambda t: -t[1])[:10]
     assert len(rel) > 150
@@ -84,8 +93,10 @@ def test_T_512x1024_bf16_outputs_and_gradients():
     Bounds = about 1.5x the measured worst case (gpurun_out/parity_report.json, key T_512x1024_bf16)."""
     m = _model(TCFG, True, "T", compute_dtype=torch.bfloat16)
     res = run_and_collect(m, (2, 3, 512, 1024), "T", device=DEV, subsample_out=4096)
-    _bf16_report(res, golden("T_512x1024_pano"), "T_512x1024_bf16", out_mean=2e-2, out_max=0.25, rel_bound=0.2,
-                 gnorm_bound=0.1)
+    # measured: outputs mean 5.6e-3 / max 3.2e-2; worst tensor patch_embed.proj.1.bias (BatchNorm-1 shift) 0.139, median
+    # over the 198 tensors 7e-3; gradient norms within 6.3 %
+    _bf16_report(res, golden("T_512x1024_pano"), "T_512x1024_bf16", out_mean=1e-2, out_max=0.06, rel_bound=0.2,
+                 gnorm_bound=0.1, nonstem_rel_bound=0.1)
 
 
 @pytest.mark.parametrize("cd", [torch.float32, torch.bfloat16])
@@ -113,15 +124,16 @@ def test_S_1024x2048_fp32():
     m = _model(SCFG, True, "S")
     res = run_and_collect(m, (1, 3, 1024, 2048), "S", device=DEV, subsample_out=4096)
     compare_to_golden(res, golden("S_1024x2048_pano"), rtol=1e-4, atol=5e-4, grad_rtol=2e-3, grad_atol_frac=1e-3,
-                      report="S_1024x2048_fp32")
+                      dx_tol=(1e-2, 5e-3), report="S_1024x2048_fp32")
 
 
 def test_S_1024x2048_bf16_outputs_and_gradients():
     """configs[4] in its stated precision (bf16) against the fp32 golden."""
     m = _model(SCFG, True, "S", compute_dtype=torch.bfloat16)
     res = run_and_collect(m, (1, 3, 1024, 2048), "S", device=DEV, subsample_out=4096)
-    _bf16_report(res, golden("S_1024x2048_pano"), "S_1024x2048_bf16", out_mean=3e-2, out_max=0.4, rel_bound=0.3,
-                 gnorm_bound=0.15)
+    # measured: outputs mean 6.5e-3 / max 3.1e-2; worst tensor 0.091 (patch_embed.proj.1.bias), median 8e-3; norms within 3 %
+    _bf16_report(res, golden("S_1024x2048_pano"), "S_1024x2048_bf16", out_mean=1.2e-2, out_max=0.06, rel_bound=0.15,
+                 gnorm_bound=0.06, nonstem_rel_bound=0.1)
 
 
 def test_batch_8_equals_four_batches_of_2_in_eval_mode():

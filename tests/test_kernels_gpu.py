@@ -612,3 +612,110 @@ def test_window_attention_module_against_the_reference_capture(ops, name, pano, 
             assert torch.allclose(p.grad.cpu(), ref, rtol=1e-4, atol=2e-5 * max(1e-3, ref.abs().max().item())), k
         else:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+
+
+# ---- the per-window fused qkv -> attention -> proj kernel (csrc/pswin_fused.hip, C = 96 / 3 heads, bf16) ------------------
+def _fused_case(B, nW, pano, mask_kind, seed):
+    from detfill import det_fill_module
+    att = po.WindowAttention(96, 7, 3)
+    det_fill_module(att, f"fz:{seed}")
+    with torch.no_grad():                       # the kernel's operands are bf16: the oracle sees the same rounded weights
+        for lin in (att.qkv, att.proj):
+            lin.weight.copy_(lin.weight.to(torch.bfloat16).float())
+    n = B * nW
+    x = det_uniform((n, 49, 96), f"fz:{seed}:x", 1.0).to(torch.bfloat16).float()
+    uv = torch.stack([det_uniform((nW, 49), f"fz:{seed}:u", math.pi), det_uniform((nW, 49), f"fz:{seed}:v", math.pi / 2)], -1)
+    uv[0, 44:] = 0.0                            # zero-uv padding slots
+    mask = None
+    if mask_kind == 3:
+        mask = torch.where(det_uniform((nW, 49, 49), f"fz:{seed}:m") > 0.4, torch.tensor(-100.0), torch.tensor(0.0))
+    elif mask_kind == 4:
+        mask = torch.where(det_uniform((B, nW, 49, 49), f"fz:{seed}:m4") > 0.4, torch.tensor(-100.0), torch.tensor(0.0))
+    gout = det_uniform((n, 49, 96), f"fz:{seed}:g", 1.0).to(torch.bfloat16).float()
+    return att, x, uv, mask, gout
+
+
+def _fused_run(ops, att_cpu, x, uv, mask, gout, B, nW, pano, mask_kind, fused):
+    """The product's WindowAttention chain on the GPU in bf16: the fused kernel or the three-kernel chain."""
+    import copy
+    from panoswintransformerobjectdetection_amd.backbone import WindowAttention, _linear
+    att = WindowAttention(96, 7, 3)
+    att.load_state_dict(att_cpu.state_dict())
+    att = att.to(DEV)
+    xd = x.to(DEV).to(torch.bfloat16).view(-1, 96).requires_grad_(True)
+    uvd = uv.to(DEV)
+    dist = ops.Tiles(ops.haversine_windows(uvd, uvd), symmetric=True) if pano else None
+    mt = None if mask is None else ops.Tiles(mask.reshape(-1, 49, 49).to(DEV))
+    nb = B * nW if mask_kind == 4 else nW
+    if fused:
+        y = ops.window_attention_fused(xd, att, dist, mt, nb)
+    else:
+        qkv = _linear(xd, att.qkv, torch.bfloat16)
+        o = ops.window_attention(qkv, att.sphere_position_alpha_table_Te, att.sphere_position_beta_table_Te, dist, mt, 3,
+                                 att.scale, nb)
+        y = _linear(o, att.proj, torch.bfloat16, use_bias=False)
+    y.backward(gout.to(DEV).to(torch.bfloat16).view(-1, 96))
+    grads = {k: p.grad.detach().float().cpu() for k, p in att.named_parameters() if p.grad is not None}
+    return y.detach().float().cpu(), xd.grad.float().cpu(), grads
+
+
+FUSED_CASES = [(2, 3, True, 0), (1, 5, False, 0), (3, 4, False, 3), (2, 3, False, 4), (2, 3, True, 3), (9, 2, True, 0),
+               (8, 15, True, 0), (1, 1, True, 0)]
+
+
+@pytest.mark.parametrize("B,nW,pano,mask_kind", FUSED_CASES)
+def test_fused_window_attention_against_the_oracle(ops, B, nW, pano, mask_kind):
+    """y = proj_nobias(attention(qkv(x))) and every gradient against the CPU oracle module on the same bf16-rounded
+    weights / inputs.  Tolerance = the bf16 attention tests' (operands q, k, v, P, O rounded to bf16, f32 accumulation)."""
+    att, x, uv, mask, gout = _fused_case(B, nW, pano, mask_kind, f"{B}{nW}{pano}{mask_kind}")
+    xo = x.clone().requires_grad_(True)
+    uvb = uv.repeat(B, 1, 1)
+    yo = att(xo, uvb, mask, pano) - att.proj.bias          # the kernel leaves the proj bias to the residual scatter kernel
+    (yo * gout).sum().backward()
+    y, dx, grads = _fused_run(ops, att, x, uv, mask, gout, B, nW, pano, mask_kind, fused=True)
+    ys = yo.abs().max().item()
+    assert torch.allclose(y.view_as(yo), yo.detach(), rtol=3e-2, atol=2e-2 * ys), (y.view_as(yo) - yo).abs().max()
+    gs = xo.grad.abs().max().item()
+    assert torch.allclose(dx.view_as(xo.grad), xo.grad, rtol=5e-2, atol=3e-2 * gs)
+    for k, p in att.named_parameters():
+        if k == "proj.bias" or (k.endswith("alpha_table_Te") and not pano):
+            continue
+        ref = p.grad
+        assert k in grads, k
+        assert torch.allclose(grads[k], ref, rtol=5e-2, atol=3e-2 * ref.abs().max().item()), (k, (grads[k] - ref).abs().max())
+
+
+@pytest.mark.parametrize("B,nW,pano,mask_kind", FUSED_CASES)
+def test_fused_window_attention_equals_the_three_kernel_chain(ops, B, nW, pano, mask_kind):
+    """Same rounding points as the unfused bf16 path (qkv, attention output rounded to bf16): outputs and gradients agree
+    to a few bf16 ulps (the accumulators start from the bias instead of adding it last), and the forward-only (no
+    tensors saved, V in the other MFMA orientation) mode returns the training mode's output."""
+    att, x, uv, mask, gout = _fused_case(B, nW, pano, mask_kind, f"{B}{nW}{pano}{mask_kind}")
+    y1, dx1, g1 = _fused_run(ops, att, x, uv, mask, gout, B, nW, pano, mask_kind, fused=True)
+    y0, dx0, g0 = _fused_run(ops, att, x, uv, mask, gout, B, nW, pano, mask_kind, fused=False)
+    assert torch.allclose(y1, y0, rtol=2e-2, atol=1e-2 * y0.abs().max().item())
+    assert torch.allclose(dx1, dx0, rtol=2e-2, atol=1e-2 * dx0.abs().max().item())
+    assert g1.keys() == g0.keys()
+    for k in g0:
+        assert torch.allclose(g1[k], g0[k], rtol=2e-2, atol=1e-2 * g0[k].abs().max().item()), k
+    # inference mode
+    from panoswintransformerobjectdetection_amd.backbone import WindowAttention
+    attd = WindowAttention(96, 7, 3)
+    attd.load_state_dict(att.state_dict())
+    attd = attd.to(DEV)
+    uvd = uv.to(DEV)
+    dist = ops.Tiles(ops.haversine_windows(uvd, uvd), symmetric=True) if pano else None
+    mt = None if mask is None else ops.Tiles(mask.reshape(-1, 49, 49).to(DEV))
+    with torch.no_grad():
+        yi = ops.window_attention_fused(x.to(DEV).to(torch.bfloat16).view(-1, 96), attd, dist, mt,
+                                        B * nW if mask_kind == 4 else nW).float().cpu()
+    assert torch.allclose(yi, y1, rtol=1e-2, atol=4e-3 * y1.abs().max().item())
+
+
+def test_fused_window_attention_rejects_what_it_is_not_built_for(ops):
+    from panoswintransformerobjectdetection_amd import PswinError, _lib
+    lib = _lib.load()
+    assert lib.pswin_win_attn_fused_supported(96, 3, _lib.BF16) == 1
+    assert lib.pswin_win_attn_fused_supported(192, 6, _lib.BF16) == 0 and lib.pswin_win_attn_fused_supported(96, 3, _lib.F32) == 0
+    x = torch.zeros(49, 192, dtype=torch.bfloat16, device=DEV)
+    assert not ops.window_attention_fused_supported(x, 6)
