@@ -133,10 +133,30 @@ __global__ __launch_bounds__(FTHREADS, 2) void win_fused_fwd_kernel(FusedArgs a)
     auto build_bias = [&](int wb, char* dst) {
         const float* dtile = a.dist ? a.dist + (size_t)(wb % a.n_dist) * (PADT * PADT) : nullptr;
         const float* mtile = a.mask ? a.mask + (size_t)(wb % a.n_mask) * (PADT * PADT) : nullptr;
-        for (int t = tid; t < FH * TOK * 16; t += FTHREADS) {
-            const int h = t / (TOK * 16), rem = t - h * (TOK * 16), i = rem >> 4, q = rem & 15;
-            const f32x4 r = bias_quad<false>(dtile, mtile, tabs + (2 * h) * TABP, tabs + (2 * h + 1) * TABP, i, 4 * q, inv_scale);
-            *reinterpret_cast<f32x4*>(dst + bias_off(h, i, q)) = r;
+        // one (query i, key quad q) per thread and iteration: the index / distance / mask quad is shared by the heads
+#pragma unroll 1
+        for (int t = tid; t < TOK * 16; t += FTHREADS) {
+            const int i = t >> 4, q = t & 15;
+            const f32x4 d4 = dtile ? *reinterpret_cast<const f32x4*>(dtile + i * PADT + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 m4 = mtile ? *reinterpret_cast<const f32x4*>(mtile + i * PADT + 4 * q) : f32x4{0.f, 0.f, 0.f, 0.f};
+            int idx[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) idx[e] = (4 * q + e < TOK) ? rel_a(i) - rel_b(4 * q + e) : 0;
+#pragma unroll
+            for (int h = 0; h < FH; ++h) {
+                const float* ta = tabs + (2 * h) * TABP;
+                const float* tb = ta + TABP;
+                f32x4 r;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    // same rounding sequence as the reference: (d * alpha + beta) [+ mask]   (HOT:255-256, 294, 301)
+                    float val = tb[idx[e]];
+                    if (dtile) val = __fadd_rn(__fmul_rn(d4[e], ta[idx[e]]), val);
+                    if (mtile) val = __fadd_rn(val, m4[e]);
+                    r[e] = (4 * q + e < TOK) ? val * inv_scale : -INFINITY;      // padded key: never receives weight
+                }
+                *reinterpret_cast<f32x4*>(dst + bias_off(h, i, q)) = r;
+            }
         }
     };
     // X rows of window (rep, wb) as operand fragments: tile t = tokens 16 t + c, step s = channels 32 s + 8 g ..; rows >= 49
@@ -175,21 +195,22 @@ __global__ __launch_bounds__(FTHREADS, 2) void win_fused_fwd_kernel(FusedArgs a)
             // 6 x 16 bytes): with 2 waves per SIMD an LDS round trip in front of every 4 MFMAs was half of the wave's life
             // (SQ_WAIT_ANY 49 %).  The scheduling barriers keep hipcc from sinking the reads back to their first use.
             u32x4 wA[2 * FKS], wB[2 * FKS];
-            auto read_w = [&](int rbase, u32x4 (&w)[2 * FKS]) {
+            f32x4 bA[2], bB[2];                       // the projection's bias quads (token-on-lane orientation) travel with the set
+            auto read_w = [&](int rbase, u32x4 (&w)[2 * FKS], f32x4 (&b)[2]) {
 #pragma unroll
                 for (int s = 0; s < FKS; ++s)
 #pragma unroll
                     for (int dt = 0; dt < 2; ++dt) w[2 * s + dt] = *reinterpret_cast<const u32x4*>(wq_l + (rbase + 16 * dt) * 192 + 64 * s);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) b[dt] = *reinterpret_cast<const f32x4*>(bq + rbase + 16 * dt + 4 * g);
             };
             // [d = 16 dt + 4 g + e][token 16 t + c] = W rows . X^T + bias  -> operand fragments per token tile
-            auto gemm_T = [&](const u32x4 (&w)[2 * FKS], int rbase, u32x4 (&frag)[4]) {
+            auto gemm_T = [&](const u32x4 (&w)[2 * FKS], const f32x4 (&b)[2], u32x4 (&frag)[4]) {
                 f32x4 acc[2][4];
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    const f32x4 b = *reinterpret_cast<const f32x4*>(bq + rbase + 16 * dt + 4 * g);
+                for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) acc[dt][t] = b;
-                }
+                    for (int t = 0; t < 4; ++t) acc[dt][t] = b[dt];
 #pragma unroll
                 for (int s = 0; s < FKS; ++s)
 #pragma unroll
@@ -203,20 +224,21 @@ __global__ __launch_bounds__(FTHREADS, 2) void win_fused_fwd_kernel(FusedArgs a)
             for (int h = 0; h < FH; ++h) {
                 // rows of Wqkv: q = h*32.., k = 96 + h*32.., v = 192 + h*32..
                 u32x4 qf[4], kf[4], vt[2][2];
-                read_w(h * HD, wA);
-                read_w(FC + h * HD, wB);
+                read_w(h * HD, wA, bA);
+                read_w(FC + h * HD, wB, bB);
+                const float bv0 = bq[2 * FC + h * HD + c], bv1 = bq[2 * FC + h * HD + 16 + c];   // V bias, feature-on-lane
                 __builtin_amdgcn_sched_barrier(0);
-                gemm_T(wA, h * HD, qf);               // Q^T
+                gemm_T(wA, bA, qf);                   // Q^T
                 __builtin_amdgcn_sched_barrier(0);
-                read_w(2 * FC + h * HD, wA);
+                read_w(2 * FC + h * HD, wA, bA);
                 __builtin_amdgcn_sched_barrier(0);
-                gemm_T(wB, FC + h * HD, kf);          // K^T
+                gemm_T(wB, bB, kf);                   // K^T
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (SAVE) {
                     // rows for the backward pass: V^T in the token-on-lane orientation as well (24 more MFMAs; the matrix
                     // pipe has the room, an LDS transpose of the other orientation costs VALU / LDS issue slots instead)
                     u32x4 vf[4];
-                    gemm_T(wA, 2 * FC + h * HD, vf);
+                    gemm_T(wA, bA, vf);
                     const rsrc_t qs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.qkv) + row0 * (3 * FC * 2) + h * HD * 2, 0,
                                                                         (TOK - 1) * 3 * FC * 2 + (2 * FC + HD) * 2, 0x00020000);
 #pragma unroll
@@ -232,7 +254,7 @@ __global__ __launch_bounds__(FTHREADS, 2) void win_fused_fwd_kernel(FusedArgs a)
                     f32x4 acc[4][2];
 #pragma unroll
                     for (int dt = 0; dt < 2; ++dt) {
-                        const float b = bq[2 * FC + h * HD + 16 * dt + c];
+                        const float b = dt ? bv1 : bv0;
 #pragma unroll
                         for (int t = 0; t < 4; ++t) acc[t][dt] = f32x4{b, b, b, b};
                     }
@@ -298,25 +320,36 @@ __global__ __launch_bounds__(FTHREADS, 2) void win_fused_fwd_kernel(FusedArgs a)
                 }
             }
             // ---- Y^T [f = 16 ft + 4 g + e][query] = Wproj . O^T, two column tiles at a time -------------------------------
+            {
+                u32x4 pw[2][2 * FH];                  // Wproj fragments of a pair of column tiles, read one pair ahead
+                auto read_p = [&](int np, u32x4 (&w)[2 * FH]) {
 #pragma unroll
-            for (int np = 0; np < FC / 32; ++np) {
-                f32x4 acc[2][4];
+                    for (int h = 0; h < FH; ++h)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                        for (int j = 0; j < 2; ++j) w[2 * h + j] = *reinterpret_cast<const u32x4*>(wp_l + 16 * (2 * np + j) * 192 + 64 * h);
+                };
+                read_p(0, pw[0]);
 #pragma unroll
-                    for (int tq = 0; tq < 4; ++tq) acc[j][tq] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int np = 0; np < FC / 32; ++np) {
+                    if (np + 1 < FC / 32) read_p(np + 1, pw[(np + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    f32x4 acc[2][4];
 #pragma unroll
-                for (int h = 0; h < FH; ++h)
+                    for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const u32x4 wf = *reinterpret_cast<const u32x4*>(wp_l + 16 * (2 * np + j) * 192 + 64 * h);
+                        for (int tq = 0; tq < 4; ++tq) acc[j][tq] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                        for (int tq = 0; tq < 4; ++tq) acc[j][tq] = mfma(wf, of[h][tq], acc[j][tq]);
-                    }
+                    for (int h = 0; h < FH; ++h)
 #pragma unroll
-                for (int tq = 0; tq < 4; ++tq)
-                    __builtin_amdgcn_raw_buffer_store_b128(row8(pack8(acc[0][tq], acc[1][tq])), ys,
-                                                           (unsigned)((16 * tq + c) * (FC * 2) + 64 * np + d0 * 2), 0, 0);
+                        for (int j = 0; j < 2; ++j)
+#pragma unroll
+                            for (int tq = 0; tq < 4; ++tq) acc[j][tq] = mfma(pw[np & 1][2 * h + j], of[h][tq], acc[j][tq]);
+#pragma unroll
+                    for (int tq = 0; tq < 4; ++tq)
+                        __builtin_amdgcn_raw_buffer_store_b128(row8(pack8(acc[0][tq], acc[1][tq])), ys,
+                                                               (unsigned)((16 * tq + c) * (FC * 2) + 64 * np + d0 * 2), 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
         const int wn = wb + gridDim.x;
