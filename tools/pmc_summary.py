@@ -10,10 +10,12 @@ per row reads back EXACT (17.7 MB counted for 17.6 MB), the wide clone of the sa
 -> factor 1 for pswin_attn_fwd / pswin_attn_bwd.  WRITE_SIZE is exact for 16 B/lane streaming stores.  The first launches (warm-up, lazily built tables) are included; they are
 the same kernels on the same shapes.
 """
-import csv, json, sys
+import csv, json, os, sys
 from collections import defaultdict
 
-KERNELS = {"attn_fwd_kernel": "pswin_attn_fwd", "attn_bwd_kernel": "pswin_attn_bwd", "attn_bwd_pair_kernel": "pswin_attn_bwd", "ln_fwd_kernel": "pswin_ln_gather_fwd",
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+KERNELS = {"win_fused_fwd_kernel": "pswin_win_attn_fused_fwd", "attn_fwd_kernel": "pswin_attn_fwd", "attn_bwd_kernel": "pswin_attn_bwd", "attn_bwd_pair_kernel": "pswin_attn_bwd", "ln_fwd_kernel": "pswin_ln_gather_fwd",
            "ln_bwd_kernel": "pswin_ln_gather_bwd", "window_gather_kernel": "pswin_window_gather",
            "window_scatter_add_kernel": "pswin_window_scatter_add"}
 
@@ -30,7 +32,7 @@ def collect(path, counter):
     return acc
 
 
-FETCH_FACTOR = {"pswin_attn_fwd": 1.0, "pswin_attn_bwd": 1.0}      # calibrated (see above); default 2.0 (wide row reads)
+FETCH_FACTOR = {"pswin_attn_fwd": 1.0, "pswin_attn_bwd": 1.0, "pswin_win_attn_fused_fwd": 2.0}      # calibrated (see above); default 2.0 (wide row reads)
 fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
 out = {}
 for name in sorted(set(fetch) | set(write)):
@@ -40,5 +42,7 @@ for name in sorted(set(fetch) | set(write)):
     out[name] = {"launches": nf, "fetch_bytes_per_launch_raw": f / max(nf, 1), "fetch_correction": k,
                  "fetch_bytes_per_launch_corrected": k * f / max(nf, 1),
                  "write_bytes_per_launch": w / max(nw, 1), "hbm_bytes_per_launch": k * f / max(nf, 1) + w / max(nw, 1)}
-json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on bench.py", "kernels": out}, open(sys.argv[3], "w"), indent=1)
+import bench  # noqa: E402  (kernel-source digest: bench.py quotes these numbers only for the same sources)
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) on bench.py", "lib_digest": bench._lib_digest(),
+           "kernels": out}, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(out, indent=1))
