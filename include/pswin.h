@@ -288,6 +288,23 @@ int pswin_stem_bn2_coefs(const float* sums, const float* prm, double count, int 
 int pswin_stem_conv1_wgrad(const float* out5, const float* xx, const void* w1p, const float* prm1, double count, int training,
                            float* dw1, float* db1, void* stream);
 
+/* Tiled bf16 GEMM for the Linear layers of stages 1-3 (qkv / proj / fc1 / fc2 / reduction, HOT:287, 309, 50-58, 575) and,
+ * through a transposed copy of the weight, their data gradients:  y[M, N] = x[M, K] . w[N, K]^T (+ bias), bf16 in / out,
+ * f32 accumulation, bias f32 [N] or NULL.  128 (or 64) x 192 macro tiles, both operands by LDS-DMA into XOR-swizzled
+ * double-buffered LDS tiles (csrc/pswin_gemm_nt.hip).  Needs N % 192 == 0, K % 64 == 0, M >= 64 (pswin_gemm_nt_supported).
+ * tile_m: 0 = choose, or 64 / 128. */
+typedef struct pswin_transpose_job {
+    const void* src; /* bf16 [rows][cols] */
+    void* dst;       /* bf16 [cols][rows] */
+    int rows;
+    int cols;
+} pswin_transpose_job;
+/* dst = src^T for every job in one launch (rows, cols multiples of 64): the per-step [K][N] bf16 copies of the Linear
+ * weights with which pswin_gemm_nt computes data gradients.  `jobs` is a HOST array, copied into the kernel arguments. */
+int pswin_transpose_jobs(const pswin_transpose_job* jobs, int n_jobs, void* stream);
+int pswin_gemm_nt_supported(long long M, int K, int N);
+int pswin_gemm_nt(const void* x, const void* w, const float* bias, void* y, long long M, int K, int N, int tile_m, void* stream);
+
 /* Streaming GEMM for the Linear layers of the high-resolution stages (qkv / proj / fc1 / fc2 of stage 0, HOT:287, 309,
  * 50-58; proj of stage 1):  y[M, N] = x[M, K] . W^T (+ bias), bf16 in / out, f32 accumulation, the whole weight resident
  * in LDS.  transpose_w == 0: w is [N, K] (nn.Linear layout, forward pass); transpose_w != 0: w is [K, N], i.e. the

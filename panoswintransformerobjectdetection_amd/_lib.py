@@ -56,6 +56,9 @@ _PROTOTYPES = {
     "pswin_stem_bn_fold": [_vp, _vp, ctypes.c_double, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _i, _vp, _vp],
     "pswin_stem_bn2_coefs": [_vp, _vp, ctypes.c_double, _i, _vp, _vp],
     "pswin_stem_conv1_wgrad": [_vp, _vp, _vp, _vp, ctypes.c_double, _i, _vp, _vp, _vp],
+    "pswin_transpose_jobs": [_vp, _i, _vp],
+    "pswin_gemm_nt_supported": [ctypes.c_longlong, _i, _i],
+    "pswin_gemm_nt": [_vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _i, _vp],
     "pswin_gemm_skinny_supported": [_i, _i],
     "pswin_gemm_skinny": [_vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _i, _vp],
     "pswin_fc1_gelu_supported": [_i, _i],
@@ -100,6 +103,11 @@ class ReduceJob(ctypes.Structure):
     """pswin_reduce_job of include/pswin.h"""
     _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("dtype", ctypes.c_int), ("rows", ctypes.c_int),
                 ("cols", ctypes.c_int), ("ld", ctypes.c_int)]
+
+
+class TransposeJob(ctypes.Structure):
+    """pswin_transpose_job of include/pswin.h"""
+    _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("rows", ctypes.c_int), ("cols", ctypes.c_int)]
 
 
 class TableGradJob(ctypes.Structure):

@@ -473,12 +473,14 @@ class SimplePanoSwinTransformer(nn.Module, DoubleModeModule):
             raise TypeError('pretrained must be a str or None')
 
     @torch.no_grad()
-    def _refresh_lowp(self, cd):
+    def _refresh_lowp(self, cd, for_backward=False):
         """bf16 copies of every Linear weight / bias on the path, refreshed by one multi-tensor cast per forward
         (instead of ~100 small cast kernels); plain attributes, never part of the state dict."""
         fp = self.__dict__.get("_flat_pair")
         if fp is not None and fp[1].dtype == cd:
             fp[1].copy_(fp[0])                      # every master weight -> its low-precision view, one kernel
+            if for_backward:
+                self._refresh_transposed(cd)
             return
         lins = [m for m in self.modules() if isinstance(m, nn.Linear) and m is not getattr(self, "abs_encoder", None)]
         src, dst = [], []
@@ -493,6 +495,29 @@ class SimplePanoSwinTransformer(nn.Module, DoubleModeModule):
                 src.append(m.bias)
                 dst.append(lp[1])
         torch._foreach_copy_(dst, src)
+        if for_backward:
+            self._refresh_transposed(cd)
+
+    @torch.no_grad()
+    def _refresh_transposed(self, cd):
+        """[K, N] copies of this step's bf16 Linear weights for the layers whose data gradient runs on pswin_gemm_nt (the
+        kernel wants both operands contraction-contiguous): one batched transpose launch per training step."""
+        if cd != torch.bfloat16 or not ops.GEMM_NT:
+            return
+        pairs = self.__dict__.get("_lowp_t_pairs")
+        if pairs is None or any(lp.data_ptr() != m.__dict__["_lowp"][0].data_ptr() for m, (lp, _) in pairs):
+            pairs = []
+            for m in self.modules():
+                lp = m.__dict__.get("_lowp") if isinstance(m, nn.Linear) else None
+                if lp is None:
+                    continue
+                N, K = lp[0].shape
+                if N % 64 == 0 and K % 192 == 0 and ops._lib.load().pswin_gemm_nt_supported(8192, N, K):
+                    t = torch.empty(K, N, dtype=cd, device=lp[0].device)
+                    m.__dict__["_lowp_t"] = t
+                    pairs.append((m, (lp[0], t)))
+            self.__dict__["_lowp_t_pairs"] = pairs
+        ops.transpose_weights([p for _, p in pairs])
 
     def _attach_flat_lowp(self, flat_master, flat_lowp):
         """Called by dp.GradReducer.flatten_parameters: all parameters are views of `flat_master`; make the low-precision
@@ -521,7 +546,7 @@ class SimplePanoSwinTransformer(nn.Module, DoubleModeModule):
             raise PswinError("SimplePanoSwinTransformer (MI355X build) needs its input on a HIP device")
         cd = self.compute_dtype
         if cd != torch.float32:
-            self._refresh_lowp(cd)
+            self._refresh_lowp(cd, for_backward=torch.is_grad_enabled())
         x, Wh, Ww = self.patch_embed(x_bchw.float(), cd)
         if self.pano_mode and self.ape:
             feat = ops.abs_pos_features(Wh, Ww, x.device)                               # HOT:926-934

@@ -1,0 +1,264 @@
+// Tiled bf16 GEMM for the Linear layers of stages 1-3 (gfx950):  Y[M, N] = X[M, K] . W[N, K]^T (+ bias)
+//
+// qkv / proj / fc1 / fc2 / reduction of PanoSwin (HOT:287, 309, 50-58, 575) at M = 4k-75k rows, K, N in 192..3072.  The
+// library kernels PyTorch-ROCm selects for these shapes run at 0.4-0.8 PFLOP/s (profiles/r01: stage-2 qkv 35.7 us against a
+// 9.7 us floor).  The same kernel serves the data gradient dX = dY . W through a transposed bf16 copy of the weight
+// (dX[M, K] = dY[M, N] . (W^T)[K, N]^T).  bf16 operands, f32 accumulation on v_mfma_f32_16x16x32_bf16: the arithmetic of the
+// library path.
+//
+// Design (CDNA4):
+//   * macro tile BM x 192, BK = 64: every N of the model is a multiple of 192 (192 .. 3072), so no column tile is padded;
+//     BM = 128 (4 waves as 2 x 2, each 64 rows x 96 columns = 24 accumulator quads) or BM = 64 for the small-M stage-3
+//     shapes (twice the tiles for the 256 CUs);
+//   * both operand tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR staging, 10 instructions per wave
+//     and k-step), double buffered, one barrier per k-step: the loads of step t+1 are issued right after the barrier that
+//     retires step t-1's reads and fly under step t's 48 MFMAs per wave; 80 KB of LDS per workgroup -> two workgroups per
+//     CU fill each other's barrier / drain bubbles;
+//   * LDS rows are 128 B (64 bf16); the 16-byte chunk index is XOR-ed with (row & 7).  LDS-DMA writes lane-linear, so the
+//     permutation is applied to the SOURCE address (lane i fetches chunk (i & 7) ^ (row & 7) of its row) and again on the
+//     fragment reads: conflict-free ds_read_b128 for 16 consecutive rows;
+//   * the product is computed transposed (A = weight rows, B = activation rows): a lane then owns 4 consecutive output
+//     columns of ONE row, two column tiles are exchanged across lane groups (v_permlane16_swap) and rows leave as 16-byte
+//     stores;
+//   * tiles are dealt to the XCDs in contiguous chunks (blockIdx % 8 = XCD under round-robin placement; speed only) with
+//     the column tile fastest, so the tiles that share an activation panel hit the same L2.
+#include "pswin_common.hpp"
+
+using namespace pswin;
+
+namespace {
+
+constexpr int BN = 192, BK = 64, NT_THREADS = 256;
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+
+__device__ inline f32x4 mfma32(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ inline unsigned pk2(float lo, float hi) { return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{lo, hi}, bf16x2_t)); }
+// lane (c, g) holds quads q0 = col[4g..4g+3], q1 = col[16+4g..16+4g+3] of a 32-column group of one row -> after the exchange
+// 8 consecutive columns starting at 8 (g >> 1) + 16 (g & 1)
+__device__ inline u32x4 pack_row8(f32x4 q0, f32x4 q1) {
+    const unsigned a0 = pk2(q0[0], q0[1]), a1 = pk2(q0[2], q0[3]), b0 = pk2(q1[0], q1[1]), b1 = pk2(q1[2], q1[3]);
+    const auto r0 = __builtin_amdgcn_permlane16_swap(a0, b0, false, false);
+    const auto r1 = __builtin_amdgcn_permlane16_swap(a1, b1, false, false);
+    return u32x4{r0[0], r1[0], r0[1], r1[1]};
+}
+
+typedef __attribute__((address_space(3))) void lds_void;
+__device__ inline void glds16(const void* gsrc, char* lds_wave_base) {
+    // 16 bytes per lane: LDS destination = wave-uniform base + lane * 16
+    __builtin_amdgcn_global_load_lds(gsrc, (lds_void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int BM>
+__global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_kernel(const unsigned short* __restrict__ X, const unsigned short* __restrict__ W,
+                                                                 const float* __restrict__ bias, unsigned short* __restrict__ Y,
+                                                                 int M, int N, int K, int tiles_m, int tiles_n) {
+    constexpr int RT = BM / 32;                       // 16-row tiles per wave (waves: 2 along M x 2 along N)
+    constexpr int CT = BN / 32;                       // 16-column tiles per wave: 6
+    constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];       // 2 stages: [A tile | B tile]
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int c = lane & 15, g = lane >> 4;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // tile of this workgroup: contiguous chunks of the tile list per XCD, column tile fastest
+    const int ntiles = tiles_m * tiles_n;
+    int t;
+    {
+        const int bid = blockIdx.x, q = ntiles / 8, r = ntiles % 8, xcd = bid % 8, loc = bid / 8;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;       // bijective for any ntiles
+    }
+    const int tm = t / tiles_n, tn = t - tm * tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // LDS-DMA source addressing: a wave instruction moves 8 rows x 128 B; lane i -> row i / 8, physical chunk i & 7, which
+    // holds the row's logical chunk (i & 7) ^ (row & 7)
+    const int lrow = lane >> 3, lch = (lane & 7) ^ (lrow & 7);                    // (row & 7) == lrow: row blocks start at multiples of 8
+    const unsigned short* a_src[BM / 32];                                         // A: BM / 8 row blocks over 4 waves
+    const unsigned short* b_src[BN / 32];                                         // B: 24 row blocks over 4 waves
+#pragma unroll
+    for (int j = 0; j < BM / 32; ++j) {
+        int row = m0 + (wave * (BM / 32) + j) * 8 + lrow;
+        row = row < M ? row : M - 1;                                              // rows past M: valid memory, results never stored
+        a_src[j] = X + (size_t)row * K + 8 * lch;
+    }
+#pragma unroll
+    for (int j = 0; j < BN / 32; ++j) b_src[j] = W + (size_t)(n0 + (wave * (BN / 32) + j) * 8 + lrow) * K + 8 * lch;
+    auto issue = [&](int kt, int stage) {
+        char* sa = smem + stage * STAGE;
+        char* sb = sa + A_BYTES;
+#pragma unroll
+        for (int j = 0; j < BM / 32; ++j) glds16(a_src[j] + kt * BK, sa + (wave * (BM / 32) + j) * 1024);
+#pragma unroll
+        for (int j = 0; j < BN / 32; ++j) glds16(b_src[j] + kt * BK, sb + (wave * (BN / 32) + j) * 1024);
+    };
+
+    f32x4 acc[RT][CT];
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+        for (int j = 0; j < CT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets: row (16 i + c) of the wave's block, logical chunk 4 ks + g -> physical chunk ^ (row & 7); the wave's
+    // row blocks start at multiples of 16, so (row & 7) = c & 7
+    const int a_lane = (wm * (BM / 2) + c) * 128, b_lane = (wn * (BN / 2) + c) * 128;
+    int choff[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) choff[ks] = ((4 * ks + g) ^ (c & 7)) << 4;
+
+    const int KT = K / BK;
+    issue(0, 0);
+    for (int kt = 0; kt < KT; ++kt) {
+        __syncthreads();                              // (vmcnt(0) + barrier) stage kt landed for every wave; stage kt-1 fully consumed
+        if (kt + 1 < KT) issue(kt + 1, (kt + 1) & 1);
+        const char* sa = smem + (kt & 1) * STAGE + a_lane;
+        const char* sb = smem + (kt & 1) * STAGE + A_BYTES + b_lane;
+        // fragments of the second 32-deep half are read under the MFMAs of the first (two register sets)
+        u32x4 af[2][RT], bf[2][CT];
+#pragma unroll
+        for (int i = 0; i < RT; ++i) af[0][i] = *reinterpret_cast<const u32x4*>(sa + i * 2048 + choff[0]);
+#pragma unroll
+        for (int j = 0; j < CT; ++j) bf[0][j] = *reinterpret_cast<const u32x4*>(sb + j * 2048 + choff[0]);
+#pragma unroll
+        for (int i = 0; i < RT; ++i) af[1][i] = *reinterpret_cast<const u32x4*>(sa + i * 2048 + choff[1]);
+#pragma unroll
+        for (int j = 0; j < CT; ++j) bf[1][j] = *reinterpret_cast<const u32x4*>(sb + j * 2048 + choff[1]);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int j = 0; j < CT; ++j)
+#pragma unroll
+                for (int i = 0; i < RT; ++i) acc[i][j] = mfma32(bf[ks][j], af[ks][i], acc[i][j]);      // transposed product: rows = output columns
+            __builtin_amdgcn_s_setprio(0);
+        }
+    }
+
+    // acc[i][j][e] = Y[row m0 + wm * BM/2 + 16 i + c][column n0 + wn * 96 + 16 j + 4 g + e]
+    const rsrc_t ys = __builtin_amdgcn_make_buffer_rsrc(Y, 0, (int)((size_t)M * N * 2), 0x00020000);
+    const int d0 = 8 * (g >> 1) + 16 * (g & 1);
+#pragma unroll
+    for (int i = 0; i < RT; ++i) {
+        const unsigned row = (unsigned)(m0 + wm * (BM / 2) + 16 * i + c);
+        const unsigned base = row < (unsigned)M ? row * (unsigned)(N * 2) + (unsigned)((n0 + wn * (BN / 2) + d0) * 2) : 0xFFFFFF00u;
+#pragma unroll
+        for (int jp = 0; jp < CT / 2; ++jp) {
+            f32x4 q0 = acc[i][2 * jp], q1 = acc[i][2 * jp + 1];
+            if (bias) {
+                q0 += *reinterpret_cast<const f32x4*>(bias + n0 + wn * (BN / 2) + 32 * jp + 4 * g);
+                q1 += *reinterpret_cast<const f32x4*>(bias + n0 + wn * (BN / 2) + 32 * jp + 16 + 4 * g);
+            }
+            const unsigned off = base == 0xFFFFFF00u ? base : base + 64u * jp;
+            __builtin_amdgcn_raw_buffer_store_b128(pack_row8(q0, q1), ys, off, 0, 0);
+        }
+    }
+}
+
+template <int BM>
+int launch_nt(const void* x, const void* w, const float* bias, void* y, int M, int N, int K, hipStream_t st) {
+    constexpr size_t lds = 2 * (size_t)(BM + BN) * BK * 2;
+    static bool configured = false;
+    if (!configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        configured = true;
+    }
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = N / BN;
+    hipLaunchKernelGGL((gemm_nt_kernel<BM>), dim3(tiles_m * tiles_n), dim3(NT_THREADS), lds, st,
+                       reinterpret_cast<const unsigned short*>(x), reinterpret_cast<const unsigned short*>(w), bias,
+                       reinterpret_cast<unsigned short*>(y), M, N, K, tiles_m, tiles_n);
+    PSWIN_LAUNCH_RET();
+}
+
+}  // namespace
+
+extern "C" {
+
+int pswin_gemm_nt_supported(long long M, int K, int N) {
+    return M >= 64 && M * (long long)(K > N ? K : N) * 2 < 0xFFFFFF00ll && K >= 64 && K % 64 == 0 && N >= 192 && N % 192 == 0;
+}
+
+/* tile_m: 0 = choose (128-row tiles unless that leaves the 256 CUs short of two rounds of tiles), or 64 / 128 */
+int pswin_gemm_nt(const void* x, const void* w, const float* bias, void* y, long long M, int K, int N, int tile_m, void* stream) {
+    PSWIN_CHECK_ARG(x && w && y && pswin_gemm_nt_supported(M, K, N) && (tile_m == 0 || tile_m == 64 || tile_m == 128));
+    PSWIN_CHECK_ARG(aligned16(x) && aligned16(w) && aligned16(y) && aligned16(bias));
+    const int m = (int)M;
+    if (tile_m == 0) tile_m = ((long long)((m + 127) / 128) * (N / BN) >= 512) ? 128 : 64;
+    if (tile_m == 128) return launch_nt<128>(x, w, bias, y, m, N, K, (hipStream_t)stream);
+    return launch_nt<64>(x, w, bias, y, m, N, K, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Batched bf16 transposes: the [K][N] copies of the Linear weights that turn the data gradient dX = dY . W into the same
+// "both operands contraction-contiguous" product as the forward pass.  One launch per step for all layers (the job table
+// travels in the kernel arguments, as pswin_reduce_jobs).
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int TJ_MAX = 64;
+struct TJob {
+    const unsigned short* src;
+    unsigned short* dst;
+    int rows, cols, first_block, tiles_c;
+};
+struct TBatch {
+    TJob job[TJ_MAX];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void transpose_jobs_kernel(const TBatch b) {
+    __shared__ unsigned short tile[64][66];
+    int lo = 0, hi = b.n - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (b.job[mid].first_block <= (int)blockIdx.x) lo = mid;
+        else hi = mid - 1;
+    }
+    const TJob& j = b.job[lo];
+    const int tl = (int)blockIdx.x - j.first_block, tr = tl / j.tiles_c, tc = tl - tr * j.tiles_c;
+    const int r0 = tr * 64, c0 = tc * 64;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;            // 32 x 8 threads, 2 elements (4 B) per thread and row
+#pragma unroll
+    for (int rr = ty; rr < 64; rr += 8) {
+        const unsigned v = *reinterpret_cast<const unsigned*>(j.src + (size_t)(r0 + rr) * j.cols + c0 + 2 * tx);
+        tile[rr][2 * tx] = (unsigned short)(v & 0xffffu);
+        tile[rr][2 * tx + 1] = (unsigned short)(v >> 16);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int cc = ty; cc < 64; cc += 8) {
+        const unsigned v = (unsigned)tile[2 * tx][cc] | ((unsigned)tile[2 * tx + 1][cc] << 16);
+        *reinterpret_cast<unsigned*>(j.dst + (size_t)(c0 + cc) * j.rows + r0 + 2 * tx) = v;
+    }
+}
+
+}  // namespace
+
+extern "C" int pswin_transpose_jobs(const pswin_transpose_job* jobs, int n_jobs, void* stream) {
+    PSWIN_CHECK_ARG(jobs && n_jobs > 0);
+    for (int j = 0; j < n_jobs; ++j)
+        PSWIN_CHECK_ARG(jobs[j].src && jobs[j].dst && jobs[j].rows > 0 && jobs[j].cols > 0 && jobs[j].rows % 64 == 0 && jobs[j].cols % 64 == 0);
+    for (int at = 0; at < n_jobs; at += TJ_MAX) {
+        TBatch b;
+        b.n = n_jobs - at < TJ_MAX ? n_jobs - at : TJ_MAX;
+        long long blocks = 0;
+        for (int j = 0; j < b.n; ++j) {
+            const pswin_transpose_job& q = jobs[at + j];
+            TJob& t = b.job[j];
+            t.src = reinterpret_cast<const unsigned short*>(q.src);
+            t.dst = reinterpret_cast<unsigned short*>(q.dst);
+            t.rows = q.rows;
+            t.cols = q.cols;
+            t.first_block = (int)blocks;
+            t.tiles_c = q.cols / 64;
+            blocks += (long long)(q.rows / 64) * (q.cols / 64);
+        }
+        PSWIN_CHECK_ARG(blocks < 0x7fffffffll);
+        hipLaunchKernelGGL(transpose_jobs_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, b);
+    }
+    PSWIN_LAUNCH_RET();
+}

@@ -16,6 +16,9 @@ from ._lib import BF16, F32, MODE_PANO, MODE_PLANAR, WPAD, WTOK, PswinError, cal
 _CACHE = {}
 # the per-window qkv -> attention -> proj kernel where it exists (C = 96); PSWIN_FUSED_ATTN=0 selects the unfused chain (A/B)
 FUSED_WINDOW_ATTENTION = os.environ.get("PSWIN_FUSED_ATTN", "1") != "0"
+# the tiled HIP GEMM (pswin_gemm_nt) for the Linear layers of stages 1-3 where it measured faster than the library kernels
+# (profiles/r02_gemm_nt_vs_library.txt); PSWIN_GEMM_NT=0: library GEMMs everywhere (A/B)
+GEMM_NT = os.environ.get("PSWIN_GEMM_NT", "1") != "0"
 
 
 def _dev_key(device):
@@ -632,6 +635,49 @@ def colsum(x2d, zero_cols=None, owners=()):
     return sum_rows(ws, n_ws // N, N, owners=owners)
 
 
+def gemm_nt_supported(x2d, n_out):
+    """bf16 rows x [n_out, K] weight on the tiled HIP GEMM (pswin_gemm_nt): the Linear layers of stages 1-3"""
+    return (x2d.dtype == torch.bfloat16 and x2d.is_cuda and x2d.dim() == 2
+            and bool(_lib.load().pswin_gemm_nt_supported(x2d.shape[0], x2d.shape[1], n_out)))
+
+
+def gemm_nt_tile(M, K, N):
+    """Row-tile height (64 / 128) with which pswin_gemm_nt computes [M, K] x [N, K]^T, or 0 = leave it to the library.
+    From profiles/r02_gemm_nt_vs_library.txt (MI355X, PanoSwin-T shapes at batch 8): the HIP kernel wins wherever the rows fill
+    the chip (M >= 8192: stages 1-2) and, for the 4-6 k rows of stage 3, on the narrow outputs with a short contraction;
+    128-row tiles once they give every CU two rounds of work."""
+    if not GEMM_NT or not bool(_lib.load().pswin_gemm_nt_supported(M, K, N)):
+        return 0
+    if M < 8192 and not (N <= 768 and K <= 1536):
+        return 0
+    return 128 if -(-M // 128) * (N // 192) >= 512 else 64
+
+
+def transpose_weights(pairs):
+    """dst = src^T for every (src [R, C], dst [C, R]) pair of contiguous bf16 matrices, one launch (pswin_transpose_jobs)."""
+    import ctypes
+    if not pairs:
+        return
+    arr = (_lib.TransposeJob * len(pairs))()
+    for a, (src, dst) in zip(arr, pairs):
+        assert src.dtype == dst.dtype == torch.bfloat16 and src.is_contiguous() and dst.is_contiguous()
+        assert dst.shape == (src.shape[1], src.shape[0])
+        a.src, a.dst, a.rows, a.cols = src.data_ptr(), dst.data_ptr(), src.shape[0], src.shape[1]
+    call("pswin_transpose_jobs", pairs[0][0], ctypes.cast(arr, ctypes.c_void_p), len(pairs))
+
+
+def gemm_nt(x2d, w, bias=None, tile_m=0):
+    """y = x2d @ w^T (+ bias): x2d [M, K] bf16, w [N, K] bf16, bias f32 [N] or None -> [M, N] bf16."""
+    x2d, w = x2d.contiguous(), w.contiguous()
+    M, K = x2d.shape
+    N = w.shape[0]
+    y = torch.empty(M, N, dtype=torch.bfloat16, device=x2d.device)
+    b = None if bias is None else bias.detach().float().contiguous()
+    call("pswin_gemm_nt", x2d, ptr(x2d), ptr(w), ptr(b), ptr(y), M, K, N, int(tile_m),
+         algo_bytes=2 * (M * K + M * N + N * K), algo_flops=2 * M * K * N)
+    return y
+
+
 def skinny_gemm_supported(x2d, n_out):
     """bf16 rows x a small weight: the shapes pswin_gemm_skinny is instantiated for (stage-0 projections, stage-1 proj)"""
     return (x2d.dtype == torch.bfloat16 and x2d.is_cuda and x2d.shape[0] >= 4096
@@ -672,16 +718,19 @@ class _LinearSplitK(torch.autograd.Function):
     explicit split-K, 55-75 us) whose fp32 partial sum also removes the bf16 -> fp32 gradient cast."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, w_lp, b_lp, zero_bias_cols=None):
+    def forward(ctx, x, weight, bias, w_lp, b_lp, zero_bias_cols=None, w_lp_t=None):
         # w_lp / b_lp: this step's bf16 copies of the fp32 master parameters (refreshed by ONE multi-tensor cast per
         # forward, see SimplePanoSwinTransformer._refresh_lowp); gradients go to the fp32 masters.
         wb = w_lp if w_lp is not None else weight.to(x.dtype)
-        ctx.save_for_backward(x, wb)
+        ctx.save_for_backward(x, wb, w_lp_t)            # w_lp_t: this step's [K, N] copy of wb (data gradient on pswin_gemm_nt) or None
         ctx.has_bias = bias is not None
         ctx.zero_bias_cols = zero_bias_cols
         ctx.weight, ctx.bias = weight, bias                 # for grad_slot / owners: dW may be summed straight into its flat slot
         if skinny_gemm_supported(x, wb.shape[0]):       # stage-0 shapes: streaming HIP GEMM, weight resident in LDS
             return skinny_gemm(x, wb, bias)
+        tile = gemm_nt_tile(x.shape[0], x.shape[1], wb.shape[0]) if x.dtype == torch.bfloat16 else 0
+        if tile:                                        # stages 1-3: tiled HIP GEMM where it beats the library kernel
+            return gemm_nt(x, wb, bias, tile)
         bb = None if bias is None else (b_lp if b_lp is not None else bias.to(x.dtype))
         M, K, N = x.shape[0], x.shape[1], wb.shape[0]
         with _lib.timed("lib_gemm_fwd", 2 * (M * K + M * N + N * K), 2 * M * K * N):
@@ -689,15 +738,16 @@ class _LinearSplitK(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        x, wb = ctx.saved_tensors
+        x, wb, wbt = ctx.saved_tensors
         dx, dw, db = linear_backward(x, wb, dy, ctx.weight, ctx.bias if ctx.has_bias else None, ctx.zero_bias_cols,
-                                     ctx.needs_input_grad[0])
-        return dx, dw, db, None, None, None
+                                     ctx.needs_input_grad[0], wbt)
+        return dx, dw, db, None, None, None, None
 
 
-def linear_backward(x, wb, dy, weight, bias, zero_bias_cols, need_dx):
+def linear_backward(x, wb, dy, weight, bias, zero_bias_cols, need_dx, wbt=None):
     """Gradients of y = x wb^T (+ bias) for bf16 rows x [M, K], wb [N, K]: (dx or None, dW f32 [N, K], dbias f32 [N] or
-    None).  weight / bias: the fp32 master parameters the gradients belong to (grad_slot / deferred reductions)."""
+    None).  weight / bias: the fp32 master parameters the gradients belong to (grad_slot / deferred reductions).
+    wbt: wb^T [K, N] if the caller keeps one (dx then runs on pswin_gemm_nt where that is the faster kernel)."""
     dy = dy.contiguous()
     M, N = dy.shape
     K = x.shape[1]
@@ -705,8 +755,11 @@ def linear_backward(x, wb, dy, weight, bias, zero_bias_cols, need_dx):
     if need_dx:
         # data gradient with the streaming kernel (weight transposed while it is staged) where that beats the library:
         # the three stage-0 shapes with 96 output columns
+        tile = gemm_nt_tile(M, N, K) if (wbt is not None and dy.dtype == torch.bfloat16) else 0
         if K == 96 and N in (96, 288, 384) and skinny_gemm_supported(dy, K):
             dx = skinny_gemm(dy, wb, None, transpose_w=True)
+        elif tile:
+            dx = gemm_nt(dy, wbt, None, tile)
         else:
             with _lib.timed("lib_gemm_dgrad", 2 * (M * K + M * N + N * K), 2 * M * K * N):
                 dx = dy @ wb
@@ -733,8 +786,8 @@ def linear(x, lin, cd, use_bias=True, zero_bias_cols=None):
     lp = lin.__dict__.get("_lowp")
     w_lp, b_lp = lp if lp is not None else (None, None)
     bias = lin.bias if use_bias else None
-    return _LinearSplitK.apply(x2, lin.weight, bias, w_lp, b_lp if use_bias else None,
-                               zero_bias_cols).view(*shp[:-1], lin.weight.shape[0])
+    return _LinearSplitK.apply(x2, lin.weight, bias, w_lp, b_lp if use_bias else None, zero_bias_cols,
+                               lin.__dict__.get("_lowp_t")).view(*shp[:-1], lin.weight.shape[0])
 
 
 class _Fc1Gelu(torch.autograd.Function):

@@ -719,3 +719,53 @@ def test_fused_window_attention_rejects_what_it_is_not_built_for(ops):
     assert lib.pswin_win_attn_fused_supported(192, 6, _lib.BF16) == 0 and lib.pswin_win_attn_fused_supported(96, 3, _lib.F32) == 0
     x = torch.zeros(49, 192, dtype=torch.bfloat16, device=DEV)
     assert not ops.window_attention_fused_supported(x, 6)
+
+
+@pytest.mark.parametrize("M,K,N,tile_m", [(19600, 384, 1152, 0), (16384, 384, 1536, 128), (4096, 3072, 768, 64), (5880, 768, 2304, 0),
+                                          (200, 64, 192, 64), (333, 192, 384, 128), (74480, 192, 576, 0), (65, 128, 192, 0)])
+@pytest.mark.parametrize("with_bias", [False, True])
+def test_gemm_nt_against_torch(ops, M, K, N, tile_m, with_bias):
+    """pswin_gemm_nt (LDS-DMA tiles, swizzled LDS, transposed-product epilogue) against an fp32 matmul of the same bf16
+    operands: one bf16 rounding of the result; ragged M (partial row tiles), every supported N / K granularity."""
+    torch.manual_seed(M + K + N)
+    x = torch.randn(M, K, device=DEV).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=DEV) / math.sqrt(K)).to(torch.bfloat16)
+    b = torch.randn(N, device=DEV) if with_bias else None
+    assert ops.gemm_nt_supported(x, N)
+    y = ops.gemm_nt(x, w, b, tile_m)
+    ref = x.float() @ w.float().t()
+    if with_bias:
+        ref = ref + b
+    assert y.shape == (M, N) and y.dtype == torch.bfloat16
+    assert torch.allclose(y.float(), ref, rtol=1e-2, atol=1e-2), (y.float() - ref).abs().max()
+    assert not ops.gemm_nt_supported(x, N + 64) and not ops.gemm_nt_supported(x[:, :K - 32].contiguous(), N)
+
+
+def test_linear_on_the_tiled_gemm_matches_the_library_path(ops):
+    """ops.linear with the tiled HIP GEMM (forward, and the data gradient through the transposed weight copy) against the
+    same layer on the library GEMMs: outputs and all three gradients within bf16 rounding."""
+    import torch.nn as nn
+    torch.manual_seed(0)
+    lin = nn.Linear(384, 1152).to(DEV)
+    lin.__dict__["_lowp"] = (lin.weight.detach().to(torch.bfloat16), lin.bias.detach().to(torch.bfloat16))
+    wt = torch.empty(384, 1152, dtype=torch.bfloat16, device=DEV)
+    ops.transpose_weights([(lin.__dict__["_lowp"][0], wt)])
+    assert torch.equal(wt, lin.__dict__["_lowp"][0].t().contiguous())
+    x = torch.randn(19600, 384, device=DEV).to(torch.bfloat16)
+    g = torch.randn(19600, 1152, device=DEV).to(torch.bfloat16)
+
+    def run(nt):
+        prev, ops.GEMM_NT = ops.GEMM_NT, nt
+        lin.__dict__["_lowp_t"] = wt if nt else None
+        try:
+            xx = x.clone().requires_grad_(True)
+            lin.weight.grad = lin.bias.grad = None
+            y = ops.linear(xx, lin, torch.bfloat16)
+            y.backward(g)
+            return y.detach().float(), xx.grad.float(), lin.weight.grad.clone(), lin.bias.grad.clone()
+        finally:
+            ops.GEMM_NT = prev
+    assert ops.gemm_nt_tile(19600, 384, 1152) == 128
+    a, b = run(True), run(False)
+    for u, v in zip(a, b):
+        assert torch.allclose(u, v, rtol=2e-2, atol=2e-2 * float(v.abs().max()))
