@@ -60,7 +60,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md; ~6.3 TB
 MFMA_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 TIMED = ("pswin_win_attn_fused_fwd", "pswin_attn_fwd", "pswin_attn_bwd", "pswin_window_gather", "pswin_window_scatter_add",
          "pswin_scatter_add_ln_fwd", "pswin_ln_gather_fwd", "pswin_ln_gather_bwd", "pswin_bias_gelu_fwd", "pswin_bias_gelu_bwd",
-         "pswin_gemm_skinny", "pswin_fc1_gelu_fwd", "pswin_fc1_gelu_bwd", "pswin_stem_conv2_fwd", "pswin_stem_conv3_fwd",
+         "pswin_gemm_skinny", "pswin_gemm_nt", "pswin_fc1_gelu_fwd", "pswin_fc1_gelu_bwd", "pswin_stem_conv2_fwd", "pswin_stem_conv3_fwd",
          "pswin_stem_conv3_bwd_stats", "pswin_stem_conv3_bwd_data", "pswin_stem_conv3_wgrad", "pswin_stem_conv2_wgrad",
          "pswin_stem_conv2_bwd", "lib_gemm_fwd", "lib_gemm_dgrad", "lib_gemm_wgrad")
 # hardware MFMA-pipe utilisation of the window-attention kernels: SQ_VALU_MFMA_BUSY_CYCLES of a separate rocprofv3 --pmc pass
@@ -145,7 +145,12 @@ def main():
                     help="use the two-graph step (backward in two pieces, all-reduce overlapped) also on one GPU")
     ap.add_argument("--kernel-steps", type=int, default=3,
                     help="eager steps run after the timed region to time individual kernels with HIP events")
+    ap.add_argument("--config", default="backbone", choices=["backbone", "maskrcnn"],
+                    help="backbone = BASELINE configs[1] (the headline); maskrcnn = configs[2]: PanoSwin-T + a minimal Mask R-CNN "
+                         "head stack (detector.py), synthetic COCO-shaped targets, end-to-end step")
     args = ap.parse_args()
+    if args.config == "maskrcnn":
+        return main_maskrcnn(args)
 
     from panoswintransformerobjectdetection_amd import SimplePanoSwinTransformer, _lib
     from panoswintransformerobjectdetection_amd.dp import GradReducer, init_distributed
@@ -389,6 +394,137 @@ def main():
             except AttributeError:
                 cores = os.cpu_count() or 1
             line["cpu_baseline"] = cpu_baseline(min(cores, 16))      # the box's CPU share for one GPU is 16
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def main_maskrcnn(args):
+    """BASELINE configs[2] / [3]: one end-to-end Mask R-CNN training step (backbone + FPN + RPN + RoI heads + AdamW), batch 2
+    per GPU unless --batch says otherwise.  The backbone's forward and backward are two hipGraphs sharing a memory pool; the
+    heads (dynamic-shaped PyTorch operators: parity unpinned, see detector.py) run eagerly between the two replays on
+    detached feature maps and hand their feature-map gradients to the second graph."""
+    from panoswintransformerobjectdetection_amd import _lib, ops as _ops
+    from panoswintransformerobjectdetection_amd.detector import MiniMaskRCNN, synthetic_targets
+    from panoswintransformerobjectdetection_amd.dp import GradReducer, init_distributed
+    from panoswintransformerobjectdetection_amd.graph import GraphedCallable, GraphedSequence
+
+    rank, local_rank, world = init_distributed(args.backend)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
+    dev = torch.device("cuda", local_rank if args.device is None else args.device)
+    torch.cuda.set_device(dev)
+    _lib.load()
+    batch = 2 if args.batch == 8 else args.batch          # configs[3]: batch = 2 per GPU
+    H = args.height
+    torch.manual_seed(0)
+    model = MiniMaskRCNN(dict(TCFG, compute_dtype=torch.bfloat16)).to(dev).train()
+    model.backbone.init_weights(None)
+    bb = model.backbone
+    red = GradReducer(bb, bucket_mb=args.bucket_mb, pack=True)
+    _ops.set_deferred_reductions(True)
+    red.broadcast_parameters(bb)
+    head_params = model.head_parameters()
+    if world > 1:
+        for p in head_params:
+            dist.broadcast(p.data, src=0)
+    opt_bb = torch.optim.AdamW([red.flatten_parameters(bb, torch.bfloat16)], lr=1e-4, weight_decay=0.05, fused=True, capturable=True)
+    opt_hd = torch.optim.AdamW(head_params, lr=1e-4, weight_decay=0.05, fused=True)
+    torch.manual_seed(1234 + rank)
+    x = torch.randn(batch, 3, H, 2 * H, device=dev)
+    targets = synthetic_targets(batch, H, 2 * H, dev, seed=rank)
+    with torch.no_grad():
+        gbuf = [torch.zeros_like(o) for o in bb(x)]
+    for p in bb.parameters():
+        p.grad = None
+    state = {}
+
+    def phase_fwd():
+        red.zero_grad()
+        state["outs"] = bb(x)
+        return state["outs"]
+
+    def phase_bwd():
+        torch.autograd.backward(state["outs"], gbuf)
+        red.pack_grads()
+        return gbuf[0]
+
+    seq = GraphedSequence([phase_fwd, phase_bwd], warmup=2)
+    g_opt = GraphedCallable(opt_bb.step, warmup=1, stream=seq.stream)
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+    parts = []
+
+    def step(record=False):
+        if record:
+            ev[0].record()
+        outs = seq.calls[0]()
+        if record:
+            ev[1].record()
+        feats = [o.detach().requires_grad_(True) for o in outs]
+        opt_hd.zero_grad(set_to_none=True)
+        losses = model.heads_loss(feats, targets, (H, 2 * H))
+        total = sum(losses.values())
+        total.backward()
+        for g, f in zip(gbuf, feats):
+            g.copy_(f.grad)
+        if record:
+            ev[2].record()
+        seq.calls[1]()
+        if record:
+            ev[3].record()
+        if world > 1:
+            flat = torch.cat([p.grad.flatten() for p in head_params])
+            dist.all_reduce(flat, op=dist.ReduceOp.AVG if dist.get_backend() == "nccl" else dist.ReduceOp.SUM)
+            if dist.get_backend() != "nccl":
+                flat /= world
+            at = 0
+            for p in head_params:
+                p.grad.copy_(flat[at:at + p.numel()].view_as(p))
+                at += p.numel()
+        red.finish()
+        g_opt()
+        opt_hd.step()
+        if record:
+            ev[4].record()
+            torch.cuda.synchronize()
+            parts.append([ev[i].elapsed_time(ev[i + 1]) for i in range(4)])
+        return total, losses
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        total, losses = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    for _ in range(3):
+        step(record=True)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.isfinite(total).item(), "non-finite loss"
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        br = [sum(p[i] for p in parts) / len(parts) for i in range(4)]
+        line = {
+            "metric": f"panoramas/sec PanoSwin-T + Mask R-CNN {H}x{2 * H} end-to-end training step", "value": round(batch * world * args.steps / elapsed, 2),
+            "unit": "panoramas/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"BASELINE.json configs[{2 if world == 1 else 3}]: PanoSwin-T backbone (HIP) + FPN + RPN + Mask R-CNN RoI heads (pure "
+                                   f"PyTorch stand-ins, parity unpinned), synthetic COCO-shaped targets, 3x{H}x{2 * H}, fwd + bwd + AdamW",
+                       "batch_per_gpu": batch, "global_batch": batch * world, "parallelism": f"dp{world}",
+                       "device": torch.cuda.get_device_name(dev)},
+            "step_breakdown_ms": {"backbone_forward_graph": round(br[0], 3), "heads_forward_backward_eager": round(br[1], 3),
+                                  "backbone_backward_graph": round(br[2], 3), "allreduce_and_optimizers": round(br[3], 3)},
+            "losses": {k: round(float(v), 4) for k, v in losses.items()},
+        }
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -1,0 +1,347 @@
+"""A minimal Mask R-CNN training step around the MI355X PanoSwin backbone (BASELINE.json configs[2]).
+
+Scope: the CALLER of the hot path, built only far enough to time an end-to-end detector step with the backbone's share in
+it.  mmcv / mmdet / torchvision are not installed, so this is a self-contained pure-PyTorch restatement of ONE pipeline with
+the reference's configuration numbers (configs/_base_/models/mask_rcnn_swin_fpn.py:21-115):
+
+  FPN (mmdet/models/necks/fpn.py: laterals 1x1, top-down nearest upsampling, 3x3 output convs, 5th level by stride-2
+  subsampling) -> RPNHead (3 anchors: scale 8, ratios 0.5 / 1 / 2, strides 4..64; MaxIoU assigner 0.7 / 0.3 / 0.3, random
+  sampler 256 @ 0.5, sigmoid cross-entropy + L1 on deltas) -> proposals (nms_pre 2000 per level, NMS 0.7, 1000 per image)
+  -> StandardRoIHead (MaxIoU 0.5, ground truth added as proposals, random sampler 512 @ 0.25; RoIAlign 7 -> Shared2FC 1024
+  -> 80 classes, cross-entropy + L1 with stds 0.1 / 0.2; RoIAlign 14 -> 4 convs + deconv -> 28 x 28 masks, BCE on the class
+  channel), called as TwoStageDetector.forward_train does (mmdet/models/detectors/two_stage.py:116-175).
+
+PARITY: unpinned.  The reference tree does not contain mmcv.ops (RoIAlign, NMS CUDA sources) nor a fixture for any head,
+so nothing here is checked against reference outputs; RoIAlign samples a fixed 2 x 2 grid per bin (the config's
+sampling_ratio = 0 is adaptive) and NMS is the exact greedy rule evaluated as a fixed-point iteration on the GPU.  The heads
+run as ordinary PyTorch-ROCm operators (MIOpen / hipBLASLt, bf16 autocast); only the backbone is hand-written HIP.
+"""
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .backbone import SimplePanoSwinTransformer
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# boxes
+# ------------------------------------------------------------------------------------------------------------------------
+def box_iou(a, b):
+    """[N, 4] x [M, 4] (x1, y1, x2, y2) -> [N, M]"""
+    area_a = (a[:, 2] - a[:, 0]).clamp(min=0) * (a[:, 3] - a[:, 1]).clamp(min=0)
+    area_b = (b[:, 2] - b[:, 0]).clamp(min=0) * (b[:, 3] - b[:, 1]).clamp(min=0)
+    lt = torch.max(a[:, None, :2], b[None, :, :2])
+    rb = torch.min(a[:, None, 2:], b[None, :, 2:])
+    wh = (rb - lt).clamp(min=0)
+    inter = wh[..., 0] * wh[..., 1]
+    return inter / (area_a[:, None] + area_b[None] - inter).clamp(min=1e-6)
+
+
+def encode_deltas(src, dst, stds):
+    """DeltaXYWHBBoxCoder.encode (means 0)"""
+    sw, sh = (src[:, 2] - src[:, 0]).clamp(min=1e-3), (src[:, 3] - src[:, 1]).clamp(min=1e-3)
+    dw, dh = (dst[:, 2] - dst[:, 0]).clamp(min=1e-3), (dst[:, 3] - dst[:, 1]).clamp(min=1e-3)
+    sx, sy = (src[:, 0] + src[:, 2]) * 0.5, (src[:, 1] + src[:, 3]) * 0.5
+    dx, dy = (dst[:, 0] + dst[:, 2]) * 0.5, (dst[:, 1] + dst[:, 3]) * 0.5
+    d = torch.stack([(dx - sx) / sw, (dy - sy) / sh, torch.log(dw / sw), torch.log(dh / sh)], 1)
+    return d / d.new_tensor(stds)
+
+
+def decode_deltas(src, deltas, stds, max_shape):
+    d = deltas * deltas.new_tensor(stds)
+    sw, sh = src[:, 2] - src[:, 0], src[:, 3] - src[:, 1]
+    sx, sy = (src[:, 0] + src[:, 2]) * 0.5, (src[:, 1] + src[:, 3]) * 0.5
+    clip = abs(math.log(16 / 1000))
+    w, h = sw * d[:, 2].clamp(-clip, clip).exp(), sh * d[:, 3].clamp(-clip, clip).exp()
+    x, y = sx + sw * d[:, 0], sy + sh * d[:, 1]
+    H, W = max_shape
+    return torch.stack([(x - w * 0.5).clamp(0, W), (y - h * 0.5).clamp(0, H), (x + w * 0.5).clamp(0, W), (y + h * 0.5).clamp(0, H)], 1)
+
+
+def nms_keep(boxes, iou_thr, iters=12):
+    """Greedy NMS on score-sorted boxes as a fixed point: keep[j] = not any(i < j: keep[i] and IoU(i, j) > thr).  Starting
+    from "keep all", every sweep fixes at least one more level of the suppression chains; `iters` sweeps of one [n, n]
+    mask-vector product each, no host synchronisation."""
+    over = torch.triu(box_iou(boxes, boxes) > iou_thr, diagonal=1).float()
+    keep = torch.ones(boxes.shape[0], device=boxes.device)
+    for _ in range(iters):
+        keep = (keep @ over == 0).float()
+    return keep.bool()
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# neck and heads
+# ------------------------------------------------------------------------------------------------------------------------
+class FPN(nn.Module):
+    def __init__(self, in_channels=(96, 192, 384, 768), out_channels=256, num_outs=5):
+        super().__init__()
+        self.lateral = nn.ModuleList(nn.Conv2d(c, out_channels, 1) for c in in_channels)
+        self.output = nn.ModuleList(nn.Conv2d(out_channels, out_channels, 3, padding=1) for _ in in_channels)
+        self.num_outs = num_outs
+
+    def forward(self, feats):
+        lat = [l(f) for l, f in zip(self.lateral, feats)]
+        for i in range(len(lat) - 1, 0, -1):
+            lat[i - 1] = lat[i - 1] + F.interpolate(lat[i], size=lat[i - 1].shape[2:], mode="nearest")
+        outs = [o(x) for o, x in zip(self.output, lat)]
+        while len(outs) < self.num_outs:
+            outs.append(F.max_pool2d(outs[-1], 1, stride=2))
+        return outs
+
+
+class RPNHead(nn.Module):
+    def __init__(self, channels=256, num_anchors=3):
+        super().__init__()
+        self.conv = nn.Conv2d(channels, channels, 3, padding=1)
+        self.cls = nn.Conv2d(channels, num_anchors, 1)
+        self.reg = nn.Conv2d(channels, num_anchors * 4, 1)
+
+    def forward(self, feats):
+        outs = []
+        for f in feats:
+            t = F.relu(self.conv(f))
+            outs.append((self.cls(t), self.reg(t)))
+        return outs
+
+
+def make_anchors(shapes, strides, device, scale=8.0, ratios=(0.5, 1.0, 2.0)):
+    """AnchorGenerator(scales=[8], ratios=[0.5, 1, 2]): per level [H * W * 3, 4], location-major (the conv output order)."""
+    out = []
+    for (H, W), s in zip(shapes, strides):
+        r = torch.tensor(ratios, device=device)
+        hr, wr = torch.sqrt(r), 1.0 / torch.sqrt(r)
+        ws, hs = s * scale * wr, s * scale * hr
+        base = torch.stack([-0.5 * ws, -0.5 * hs, 0.5 * ws, 0.5 * hs], 1)                         # centred on the cell corner
+        sy, sx = torch.meshgrid(torch.arange(H, device=device) * s, torch.arange(W, device=device) * s, indexing="ij")
+        shift = torch.stack([sx, sy, sx, sy], -1).reshape(-1, 1, 4).float()
+        out.append((shift + base[None]).reshape(-1, 4))
+    return out
+
+
+class BBoxHead(nn.Module):
+    def __init__(self, channels=256, roi=7, fc=1024, num_classes=80):
+        super().__init__()
+        self.fc1, self.fc2 = nn.Linear(channels * roi * roi, fc), nn.Linear(fc, fc)
+        self.cls, self.reg = nn.Linear(fc, num_classes + 1), nn.Linear(fc, num_classes * 4)
+
+    def forward(self, x):
+        x = F.relu(self.fc2(F.relu(self.fc1(x.flatten(1)))))
+        return self.cls(x), self.reg(x)
+
+
+class MaskHead(nn.Module):
+    def __init__(self, channels=256, num_convs=4, num_classes=80):
+        super().__init__()
+        self.convs = nn.ModuleList(nn.Conv2d(channels, channels, 3, padding=1) for _ in range(num_convs))
+        self.up = nn.ConvTranspose2d(channels, channels, 2, stride=2)
+        self.logits = nn.Conv2d(channels, num_classes, 1)
+
+    def forward(self, x):
+        for c in self.convs:
+            x = F.relu(c(x))
+        return self.logits(F.relu(self.up(x)))
+
+
+def roi_align(feats, strides, rois, out_size, finest_scale=56, samples=2):
+    """SingleRoIExtractor + RoIAlign over 4 FPN levels.  rois [B, n, 4] in image pixels (the same number per image) ->
+    [B * n, C, out, out].  One grid_sample per level over the whole batch; a fixed samples x samples grid per output bin,
+    averaged; every RoI takes its value from the level its scale maps to (finest_scale = 56, as mmdet)."""
+    B, n, _ = rois.shape
+    scale = torch.sqrt(((rois[..., 2] - rois[..., 0]) * (rois[..., 3] - rois[..., 1])).clamp(min=1e-6))
+    lvl = torch.floor(torch.log2(scale / finest_scale + 1e-6)).clamp(0, len(feats) - 1).long()      # [B, n]
+    S = out_size * samples
+    t = (torch.arange(S, device=rois.device, dtype=torch.float32) + 0.5) / S                      # sample positions in [0, 1]
+    out = None
+    for l, (f, s) in enumerate(zip(feats, strides)):
+        _, C, H, W = f.shape
+        x1, y1, x2, y2 = [rois[..., i] / s for i in range(4)]
+        gx = (x1[..., None] + (x2 - x1).clamp(min=1.0)[..., None] * t) / W * 2 - 1                # [B, n, S]
+        gy = (y1[..., None] + (y2 - y1).clamp(min=1.0)[..., None] * t) / H * 2 - 1
+        grid = torch.stack([gx[:, :, None, :].expand(B, n, S, S), gy[:, :, :, None].expand(B, n, S, S)], -1).reshape(B, n * S, S, 2)
+        smp = F.grid_sample(f, grid.to(f.dtype), mode="bilinear", padding_mode="border", align_corners=False)   # [B, C, n*S, S]
+        smp = F.avg_pool2d(smp.view(B, C, n, S, S).permute(0, 2, 1, 3, 4).reshape(B * n, C, S, S), samples)
+        w = (lvl == l).reshape(B * n, 1, 1, 1).to(smp.dtype)
+        out = smp * w if out is None else out + smp * w
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# the detector
+# ------------------------------------------------------------------------------------------------------------------------
+class MiniMaskRCNN(nn.Module):
+    """backbone -> FPN -> RPN -> RoI heads with the train_cfg numbers of configs/_base_/models/mask_rcnn_swin_fpn.py.
+    `heads_loss(feats, targets)` is everything behind the backbone; `forward_train` = backbone + heads_loss."""
+
+    STRIDES = (4, 8, 16, 32, 64)
+
+    def __init__(self, backbone_cfg, num_classes=80):
+        super().__init__()
+        self.backbone = SimplePanoSwinTransformer(**backbone_cfg)
+        c = self.backbone.num_features
+        self.neck = FPN(c, 256, 5)
+        self.rpn = RPNHead(256, 3)
+        self.bbox_head = BBoxHead(256, 7, 1024, num_classes)
+        self.mask_head = MaskHead(256, 4, num_classes)
+        self.num_classes = num_classes
+        self.rpn_cfg = dict(pos=0.7, neg=0.3, min_pos=0.3, num=256, pos_fraction=0.5, nms_pre=2000, max_per_img=1000, nms=0.7)
+        self.rcnn_cfg = dict(pos=0.5, num=512, pos_fraction=0.25, mask_size=28)
+        for part in (self.neck, self.rpn, self.mask_head):
+            for m in part.modules():
+                if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+                    nn.init.normal_(m.weight, std=0.01)
+                    nn.init.zeros_(m.bias)
+
+    def head_parameters(self):
+        bb = {id(p) for p in self.backbone.parameters()}
+        return [p for p in self.parameters() if id(p) not in bb]
+
+    # -- RPN ----------------------------------------------------------------------------------------------------------
+    def _rpn_losses_and_proposals(self, rpn_outs, anchors, targets, img_hw):
+        cfg = self.rpn_cfg
+        B = rpn_outs[0][0].shape[0]
+        flat_a = torch.cat(anchors, 0)
+        cls_all = torch.cat([c.permute(0, 2, 3, 1).reshape(B, -1) for c, _ in rpn_outs], 1).float()          # [B, A]
+        reg_all = torch.cat([r.permute(0, 2, 3, 1).reshape(B, -1, 4) for _, r in rpn_outs], 1).float()       # [B, A, 4]
+        loss_cls = loss_reg = cls_all.new_zeros(())
+        n_pos_max, n_tot = int(cfg["num"] * cfg["pos_fraction"]), cfg["num"]
+        proposals = []
+        for b in range(B):
+            gt = targets[b]["boxes"]
+            iou = box_iou(flat_a, gt)                                                             # [A, G]
+            best, arg = iou.max(1)
+            label = torch.full_like(best, -1)
+            label[best < cfg["neg"]] = 0
+            label[best >= cfg["pos"]] = 1
+            gbest = iou.max(0)[0]                                                                 # low-quality matches
+            lq = ((iou == gbest[None]) & (gbest[None] >= cfg["min_pos"])).any(1)
+            label[lq] = 1
+            # random sampling with static shapes: rank by a random key, positives first
+            key = torch.rand_like(best)
+            pos_rank = torch.argsort(torch.where(label == 1, key, key + 2))[:n_pos_max]
+            pos_valid = label[pos_rank] == 1
+            neg_rank = torch.argsort(torch.where(label == 0, key, key + 2))[:n_tot]
+            n_pos = pos_valid.sum()
+            neg_valid = (label[neg_rank] == 0) & (torch.arange(n_tot, device=key.device) < (n_tot - n_pos))
+            idx = torch.cat([pos_rank, neg_rank])
+            valid = torch.cat([pos_valid, neg_valid]).float()
+            tgt = torch.cat([torch.ones_like(pos_valid, dtype=torch.float32), torch.zeros(n_tot, device=key.device)])
+            avg = valid.sum().clamp(min=1)
+            loss_cls = loss_cls + (F.binary_cross_entropy_with_logits(cls_all[b, idx], tgt, reduction="none") * valid).sum() / avg
+            d_t = encode_deltas(flat_a[pos_rank], gt[arg[pos_rank]], (1.0, 1.0, 1.0, 1.0))
+            loss_reg = loss_reg + ((reg_all[b, pos_rank] - d_t).abs().sum(1) * pos_valid.float()).sum() / avg
+            # proposals (no gradient): per level top nms_pre, decode, NMS, then the best max_per_img over the levels
+            with torch.no_grad():
+                boxes_l, scores_l, at = [], [], 0
+                for a_l in anchors:
+                    n = a_l.shape[0]
+                    sc = cls_all[b, at:at + n]
+                    k = min(cfg["nms_pre"], n)
+                    top, ti = sc.topk(k)
+                    bx = decode_deltas(a_l[ti], reg_all[b, at:at + n][ti], (1.0, 1.0, 1.0, 1.0), img_hw)
+                    keep = nms_keep(bx, cfg["nms"])
+                    boxes_l.append(bx)
+                    scores_l.append(torch.where(keep, top, top.new_full((), -1e4)))
+                    at += n
+                bx, sc = torch.cat(boxes_l), torch.cat(scores_l)
+                ti = sc.topk(min(cfg["max_per_img"], sc.numel()))[1]
+                proposals.append(bx[ti])
+        return loss_cls / B, loss_reg / B, proposals
+
+    # -- RoI heads ------------------------------------------------------------------------------------------------------
+    def _roi_losses(self, feats, proposals, targets, img_hw):
+        cfg = self.rcnn_cfg
+        n_tot, n_pos_max = cfg["num"], int(cfg["num"] * cfg["pos_fraction"])
+        rois, labels, reg_t, pos_valid_all, gt_idx_all = [], [], [], [], []
+        with torch.no_grad():
+            for b, props in enumerate(proposals):
+                gt, gl = targets[b]["boxes"], targets[b]["labels"]
+                cand = torch.cat([gt, props], 0)                                                  # add_gt_as_proposals
+                iou = box_iou(cand, gt)
+                best, arg = iou.max(1)
+                is_pos = best >= cfg["pos"]
+                key = torch.rand_like(best)
+                pos_rank = torch.argsort(torch.where(is_pos, key, key + 2))[:n_pos_max]
+                pos_valid = is_pos[pos_rank]
+                neg_rank = torch.argsort(torch.where(~is_pos, key, key + 2))[:n_tot - n_pos_max]
+                idx = torch.cat([pos_rank, neg_rank])
+                rois.append(cand[idx])
+                lab = torch.where(torch.cat([pos_valid, torch.zeros_like(neg_rank, dtype=torch.bool)]), gl[arg[idx]],
+                                  torch.full_like(idx, self.num_classes))                          # background = num_classes
+                labels.append(lab)
+                reg_t.append(encode_deltas(cand[pos_rank], gt[arg[pos_rank]], (0.1, 0.1, 0.2, 0.2)))
+                pos_valid_all.append(pos_valid)
+                gt_idx_all.append(arg[pos_rank])
+        rois_b, labels_c = torch.stack(rois), torch.cat(labels)                                  # [B, n_tot, 4], [B * n_tot]
+        B = len(proposals)
+        x = roi_align(feats[:4], self.STRIDES[:4], rois_b, 7)
+        cls, reg = self.bbox_head(x.to(feats[0].dtype))
+        loss_cls = F.cross_entropy(cls.float(), labels_c)
+        pos_sel = torch.cat([torch.arange(n_pos_max, device=rois_b.device) + b * n_tot for b in range(B)])
+        pv = torch.cat(pos_valid_all).float()
+        pl = labels_c[pos_sel].clamp(max=self.num_classes - 1)
+        ar = torch.arange(pos_sel.numel(), device=reg.device)
+        reg_p = reg.float()[pos_sel].view(-1, self.num_classes, 4)[ar, pl]
+        loss_bbox = ((reg_p - torch.cat(reg_t)).abs().sum(1) * pv).sum() / (B * n_tot)
+        # masks on the positive RoIs (the first n_pos_max of every image)
+        xm = roi_align(feats[:4], self.STRIDES[:4], rois_b[:, :n_pos_max], 14)
+        logits = self.mask_head(xm.to(feats[0].dtype)).float()                                    # [B * P, classes, 28, 28]
+        logit_c = logits[ar, pl]
+        with torch.no_grad():
+            mt = []
+            ms = cfg["mask_size"]
+            t = (torch.arange(ms, device=rois_b.device, dtype=torch.float32) + 0.5) / ms
+            H, W = img_hw
+            for b in range(B):
+                r = rois_b[b, :n_pos_max]
+                gx = (r[:, 0:1] + (r[:, 2:3] - r[:, 0:1]) * t[None]) / W * 2 - 1
+                gy = (r[:, 1:2] + (r[:, 3:4] - r[:, 1:2]) * t[None]) / H * 2 - 1
+                grid = torch.stack([gx[:, None, :].expand(-1, ms, ms), gy[:, :, None].expand(-1, ms, ms)], -1).reshape(1, -1, ms, 2)
+                gm = targets[b]["masks"].float()[None]                                            # [1, G, H, W]: all gt bitmaps as channels
+                smp = F.grid_sample(gm, grid, mode="bilinear", padding_mode="zeros", align_corners=False)   # [1, G, P * ms, ms]
+                smp = smp[0].view(gm.shape[1], n_pos_max, ms, ms)
+                mt.append((smp[gt_idx_all[b], torch.arange(n_pos_max, device=smp.device)] >= 0.5).float())
+            mt = torch.cat(mt)
+        lm = F.binary_cross_entropy_with_logits(logit_c, mt, reduction="none").mean((1, 2))
+        loss_mask = (lm * pv).sum() / pv.sum().clamp(min=1)
+        return loss_cls, loss_bbox, loss_mask
+
+    def heads_loss(self, feats, targets, img_hw):
+        """Everything behind the backbone: dict of the 5 Mask R-CNN losses (two_stage.py:116-175)."""
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=feats[0].is_cuda):
+            fpn = self.neck([f for f in feats])
+            rpn_outs = self.rpn(fpn)
+        anchors = make_anchors([f.shape[2:] for f in fpn], self.STRIDES, feats[0].device)
+        l_rpn_cls, l_rpn_reg, proposals = self._rpn_losses_and_proposals(rpn_outs, anchors, targets, img_hw)
+        with torch.autocast("cuda", dtype=torch.bfloat16, enabled=feats[0].is_cuda):
+            l_cls, l_bbox, l_mask = self._roi_losses(fpn, proposals, targets, img_hw)
+        return {"loss_rpn_cls": l_rpn_cls, "loss_rpn_bbox": l_rpn_reg, "loss_cls": l_cls, "loss_bbox": l_bbox, "loss_mask": l_mask}
+
+    def forward_train(self, img, targets):
+        return self.heads_loss(self.backbone(img), targets, img.shape[2:])
+
+
+def synthetic_targets(batch, H, W, device, num_classes=80, seed=0):
+    """COCO-shaped synthetic targets as the reference's own detector tests build them (tests/test_models/test_forward.py:
+    326-392, _demo_mm_inputs: RandomState(0), 1-9 boxes per image from uniform centre / size, labels in [1, classes),
+    random bitmap masks); masks here are the box interiors with a random 8 x 8 pattern so that they are learnable shapes
+    of the right size rather than 50 % noise at full resolution."""
+    import numpy as np
+    rng = np.random.RandomState(seed)
+    out = []
+    for _ in range(batch):
+        n = rng.randint(1, 10)
+        cx, cy, bw, bh = rng.rand(n, 4).T
+        x1, y1 = ((cx * W) - (W * bw / 2)).clip(0, W), ((cy * H) - (H * bh / 2)).clip(0, H)
+        x2, y2 = ((cx * W) + (W * bw / 2)).clip(0, W), ((cy * H) + (H * bh / 2)).clip(0, H)
+        boxes = np.stack([x1, y1, np.maximum(x2, x1 + 2), np.maximum(y2, y1 + 2)], 1).astype(np.float32)
+        labels = rng.randint(1, num_classes, size=n)
+        masks = np.zeros((n, H, W), dtype=np.uint8)
+        for i, (a, b, c, d) in enumerate(boxes.astype(int)):
+            pat = rng.randint(0, 2, (8, 8)).astype(np.uint8)
+            hh, ww = max(d - b, 1), max(c - a, 1)
+            masks[i, b:b + hh, a:a + ww] = np.kron(pat, np.ones((hh // 8 + 1, ww // 8 + 1), dtype=np.uint8))[:hh, :ww]
+        out.append({"boxes": torch.from_numpy(boxes).to(device), "labels": torch.from_numpy(labels).long().to(device),
+                    "masks": torch.from_numpy(masks).to(device)})
+    return out
