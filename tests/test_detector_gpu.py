@@ -21,22 +21,39 @@ def test_mask_rcnn_step_and_backbone_gradient_hand_off(cd):
     x = torch.randn(B, 3, H, W, device=DEV)
     tg = synthetic_targets(B, H, W, DEV)
 
-    torch.manual_seed(7)                                       # the samplers draw random keys: same draws in both runs
-    losses = m.forward_train(x, tg)
+    outs = m.backbone(x)
+    for o in outs:
+        o.retain_grad()                                        # the feature-map gradients the heads send back
+    losses = m.heads_loss(outs, tg, (H, W))
     total = sum(losses.values())
     assert torch.isfinite(total) and all(torch.isfinite(v) and v >= 0 for v in losses.values())
     total.backward()
+    G = [o.grad.detach().clone() for o in outs]
     ref = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
-    assert all(torch.isfinite(g).all() for g in ref.values())
+    assert all(torch.isfinite(g).all() for g in ref.values()) and all(torch.isfinite(g).all() and g.abs().sum() > 0 for g in G)
     assert sum(float(g.abs().sum()) > 0 for k, g in ref.items() if k.startswith("backbone.")) > 100
+    assert all(ref[k].abs().sum() > 0 for k in ref if not k.startswith("backbone."))
 
+    # the arrangement bench.py --config maskrcnn replays: backbone forward | heads on detached maps | backbone backward fed
+    # with the heads' feature-map gradients.  Same gradients G -> same backbone parameter gradients as the end-to-end pass.
     for p in m.parameters():
         p.grad = None
-    outs = m.backbone(x)
-    feats = [o.detach().requires_grad_(True) for o in outs]
-    torch.manual_seed(7)
-    sum(m.heads_loss(feats, tg, (H, W)).values()).backward()
-    torch.autograd.backward(outs, [f.grad for f in feats])
-    for k, p in m.named_parameters():
-        tol = 1e-5 if cd == torch.float32 else 1e-2
-        assert torch.allclose(p.grad, ref[k], rtol=tol, atol=tol * float(ref[k].abs().max()) + 1e-12), k
+    outs2 = m.backbone(x)
+    torch.autograd.backward(outs2, G)
+    from _util import ZERO_GRAD_KEYS, record
+    worst = {"stem": (0.0, ""), "rest": (0.0, "")}
+    for k, p in m.backbone.named_parameters():
+        if any(z in k for z in ZERO_GRAD_KEYS):
+            continue
+        r = ref["backbone." + k]
+        err = float((p.grad - r).norm() / r.norm().clamp_min(1e-30))
+        grp = "stem" if k.startswith("patch_embed.proj") else "rest"
+        if err > worst[grp][0]:
+            worst[grp] = (err, k)
+    record(f"detector_hand_off_{'fp32' if cd == torch.float32 else 'bf16'}", stem_rel=worst["stem"][0], stem_key=worst["stem"][1],
+           rest_rel=worst["rest"][0], rest_key=worst["rest"][1])
+    # behind the stem: this repository's kernels (fixed summation order) + library GEMMs; the small stem of this tiny model
+    # runs on MIOpen convolutions, whose backward-weights kernels are not bitwise reproducible from call to call
+    assert worst["rest"][0] < 1e-5, worst
+    assert worst["stem"][0] < 1e-3, worst
+    assert all(p.grad is None for k, p in m.named_parameters() if not k.startswith("backbone."))
