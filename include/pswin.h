@@ -293,6 +293,15 @@ int pswin_stem_conv1_wgrad(const float* out5, const float* xx, const void* w1p, 
  * f32 accumulation, bias f32 [N] or NULL.  128 (or 64) x 192 macro tiles, both operands by LDS-DMA into XOR-swizzled
  * double-buffered LDS tiles (csrc/pswin_gemm_nt.hip).  Needs N % 192 == 0, K % 64 == 0, M >= 64 (pswin_gemm_nt_supported).
  * tile_m: 0 = choose, or 64 / 128. */
+/* Weight gradient of a Linear layer: partial[s][n][k] = sum over the rows m of split s of dy[m][n] * x[m][k]  (dW = dY^T X,
+ * autograd of HOT:287, 309, 50-58, 575), bf16 operands, f32 partial sums, one [N, K] slab per row split; the caller adds
+ * the `splits` slabs (pswin_reduce_jobs).  Both operands are staged row-major in LDS by LDS-DMA and read TRANSPOSED
+ * (ds_read_b64_tr_b16): csrc/pswin_gemm_tn.hip.  Needs (K % 128 == 0 and N % 192 == 0) or (K % 192 == 0 and N % 128 == 0);
+ * 1 <= splits <= M / 64 (pswin_gemm_tn_splits suggests one); partial: f32 [splits, N, K]. */
+int pswin_gemm_tn_supported(long long M, int N, int K);
+int pswin_gemm_tn_splits(long long M, int N, int K);
+int pswin_gemm_tn(const void* dy, const void* x, float* partial, long long M, int N, int K, int splits, void* stream);
+
 typedef struct pswin_transpose_job {
     const void* src; /* bf16 [rows][cols] */
     void* dst;       /* bf16 [cols][rows] */

@@ -56,6 +56,9 @@ _PROTOTYPES = {
     "pswin_stem_bn_fold": [_vp, _vp, ctypes.c_double, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _i, _vp, _vp],
     "pswin_stem_bn2_coefs": [_vp, _vp, ctypes.c_double, _i, _vp, _vp],
     "pswin_stem_conv1_wgrad": [_vp, _vp, _vp, _vp, ctypes.c_double, _i, _vp, _vp, _vp],
+    "pswin_gemm_tn_supported": [ctypes.c_longlong, _i, _i],
+    "pswin_gemm_tn_splits": [ctypes.c_longlong, _i, _i],
+    "pswin_gemm_tn": [_vp, _vp, _vp, ctypes.c_longlong, _i, _i, _i, _vp],
     "pswin_transpose_jobs": [_vp, _i, _vp],
     "pswin_gemm_nt_supported": [ctypes.c_longlong, _i, _i],
     "pswin_gemm_nt": [_vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _i, _vp],

@@ -19,6 +19,10 @@ FUSED_WINDOW_ATTENTION = os.environ.get("PSWIN_FUSED_ATTN", "1") != "0"
 # the tiled HIP GEMM (pswin_gemm_nt) for the Linear layers of stages 1-3 where it measured faster than the library kernels
 # (profiles/r02_gemm_nt_vs_library.txt); PSWIN_GEMM_NT=0: library GEMMs everywhere (A/B)
 GEMM_NT = os.environ.get("PSWIN_GEMM_NT", "1") != "0"
+# the HIP weight-gradient kernel (pswin_gemm_tn): faster than the library's batched split-K GEMM kernel for kernel on most
+# stage 1-3 shapes (profiles/r02_gemm_tn_split_sweep.txt), but its f32 partial slabs cost the step what the kernel gains
+# (same-box A/B, profiles/r02_ab_gemm.txt): opt-in
+GEMM_TN = os.environ.get("PSWIN_GEMM_TN", "0") != "0"
 
 
 def _dev_key(device):
@@ -666,6 +670,26 @@ def transpose_weights(pairs):
     call("pswin_transpose_jobs", pairs[0][0], ctypes.cast(arr, ctypes.c_void_p), len(pairs))
 
 
+def gemm_tn_splits(M, N, K):
+    """Row splits for the weight-gradient kernel pswin_gemm_tn on dy [M, N], x [M, K], or 0 = leave it to the library."""
+    if not GEMM_TN or M < 4096 or not bool(_lib.load().pswin_gemm_tn_supported(M, N, K)):
+        return 0
+    if 2 * N == K:          # PatchMerging's reduction (4C -> 2C): the library's batched GEMM measured 5-10 % faster
+        return 0
+    return int(_lib.load().pswin_gemm_tn_splits(M, N, K))
+
+
+def gemm_tn(dy, x, splits):
+    """f32 [splits, N, K] partial sums of dy^T x over `splits` row ranges (dy [M, N], x [M, K] bf16)."""
+    dy, x = dy.contiguous(), x.contiguous()
+    M, N = dy.shape
+    K = x.shape[1]
+    part = torch.empty(splits, N, K, dtype=torch.float32, device=x.device)
+    call("pswin_gemm_tn", x, ptr(dy), ptr(x), ptr(part), M, N, K, int(splits),
+         algo_bytes=2 * (M * K + M * N) + 4 * splits * N * K, algo_flops=2 * M * K * N)
+    return part
+
+
 def gemm_nt(x2d, w, bias=None, tile_m=0):
     """y = x2d @ w^T (+ bias): x2d [M, K] bf16, w [N, K] bf16, bias f32 [N] or None -> [M, N] bf16."""
     x2d, w = x2d.contiguous(), w.contiguous()
@@ -763,14 +787,20 @@ def linear_backward(x, wb, dy, weight, bias, zero_bias_cols, need_dx, wbt=None):
         else:
             with _lib.timed("lib_gemm_dgrad", 2 * (M * K + M * N + N * K), 2 * M * K * N):
                 dx = dy @ wb
-    ch = _pick_split(M, -(-N // 64) * -(-K // 64))
-    with _lib.timed("lib_gemm_wgrad", 2 * (M * K + M * N) + 4 * N * K, 2 * M * K * N):
-        if ch > 1:
-            part = torch.bmm(dy.view(ch, M // ch, N).transpose(1, 2), x.view(ch, M // ch, K))
-        else:
-            dw = (dy.t() @ x).float()
+    sp = gemm_tn_splits(M, N, K) if dy.dtype == torch.bfloat16 else 0
+    if sp:                                                   # stages 1-3: HIP weight-gradient kernel, f32 partial slabs
+        part, ch = gemm_tn(dy, x, sp), sp
+    else:
+        ch = _pick_split(M, -(-N // 64) * -(-K // 64))
+        with _lib.timed("lib_gemm_wgrad", 2 * (M * K + M * N) + 4 * N * K, 2 * M * K * N):
+            if ch > 1:
+                part = torch.bmm(dy.view(ch, M // ch, N).transpose(1, 2), x.view(ch, M // ch, K))
+            else:
+                dw = (dy.t() @ x).float()
     if ch > 1:
         dw = sum_rows(part, ch, N * K, out=grad_slot(weight), owners=(weight,)).view(N, K)
+    elif sp:
+        dw = part.view(N, K)
     db = colsum(dy, zero_bias_cols, owners=(bias,)) if bias is not None else None
     return dx, dw, db
 

@@ -769,3 +769,25 @@ def test_linear_on_the_tiled_gemm_matches_the_library_path(ops):
     a, b = run(True), run(False)
     for u, v in zip(a, b):
         assert torch.allclose(u, v, rtol=2e-2, atol=2e-2 * float(v.abs().max()))
+
+
+@pytest.mark.parametrize("M,N,K,splits", [(19600, 1152, 384, 0), (16384, 384, 1536, 0), (4096, 768, 3072, 7), (5880, 2304, 768, 0),
+                                          (333, 192, 128, 3), (64, 128, 192, 1), (74480, 768, 192, 0), (1000, 384, 384, 15)])
+def test_gemm_tn_against_torch(ops, M, N, K, splits):
+    """pswin_gemm_tn (LDS-DMA slabs, both operands read transposed from LDS, f32 partial slabs per row split) against an
+    fp32 matmul of the same bf16 operands; ragged M (the last slab of the last split reads past M: zeros), both macro-tile
+    orientations."""
+    from panoswintransformerobjectdetection_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(M + N + K)
+    dy = torch.randn(M, N, device=DEV).to(torch.bfloat16)
+    x = torch.randn(M, K, device=DEV).to(torch.bfloat16)
+    assert lib.pswin_gemm_tn_supported(M, N, K) == 1
+    sp = splits or lib.pswin_gemm_tn_splits(M, N, K)
+    assert 1 <= sp <= M // 64
+    part = ops.gemm_tn(dy, x, sp)
+    assert part.shape == (sp, N, K) and part.dtype == torch.float32
+    got = part.sum(0)
+    ref = dy.float().t() @ x.float()
+    assert torch.allclose(got, ref, rtol=2e-3, atol=2e-3 * float(ref.abs().max())), (got - ref).abs().max()
+    assert lib.pswin_gemm_tn_supported(M, 576, 192) == 0 and lib.pswin_gemm_tn_supported(M, N + 64, K) == 0
