@@ -30,6 +30,8 @@
 //     softmax / accumulation.
 //   * Q/K/V/dO fragments are loaded straight from HBM in MFMA operand layout (lane = row & 15, 8 contiguous
 //     head-dim elements per lane = one 16-byte load for bf16): no staging pass for the row-wise operands.
+#include <cstdlib>
+
 #include "pswin_attn_frag.hpp"
 
 using namespace pswin;
@@ -802,7 +804,10 @@ __global__ __launch_bounds__(256) void dtab_final_kernel(const TBatch b) {
 // PanoSwin-T stage shapes on MI355X (tools/bench_attn.py): forward (2 waves/SIMD) ~1100 items, backward
 // (1 wave/SIMD, heavier items) ~600 items.
 inline int pick_chunks(int reps, int nb, int heads, bool backward) {
-    const long long target = backward ? 600 : 1100;
+    // PSWIN_ATTN_TARGET_FWD / _BWD: tuning override for sweeps inside the full step (tools/ab_attn_chunks.sh)
+    static const long long tf = getenv("PSWIN_ATTN_TARGET_FWD") ? atoll(getenv("PSWIN_ATTN_TARGET_FWD")) : 1100;
+    static const long long tb = getenv("PSWIN_ATTN_TARGET_BWD") ? atoll(getenv("PSWIN_ATTN_TARGET_BWD")) : 600;
+    const long long target = backward ? tb : tf;
     int best = reps;
     for (int ch = 1; ch <= reps; ++ch) {
         if (reps % ch) continue;
