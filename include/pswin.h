@@ -313,6 +313,14 @@ typedef struct pswin_transpose_job {
 int pswin_transpose_jobs(const pswin_transpose_job* jobs, int n_jobs, void* stream);
 int pswin_gemm_nt_supported(long long M, int K, int N);
 int pswin_gemm_nt(const void* x, const void* w, const float* bias, void* y, long long M, int K, int N, int tile_m, void* stream);
+/* The data gradient of the Mlp's fc2 fused with the backward of fc1's bias + nn.GELU (HOT:50-58):
+ *   dpre[M, N] = (dy[M, K] . w_t[N, K]^T) * gelu'(pre + bias),   partial[t][n] = sum over the rows of row tile t of dpre[., n]
+ * with w_t = fc2.weight^T ([hidden N, K]), pre = the pre-activation fc1(x) without bias, bias = fc1.bias (f32 [N] or NULL).
+ * dL/dh is never written.  partial: f32 [pswin_gemm_nt_partial_rows(M, tile_m), N]; its column sums are the fc1 bias
+ * gradient (pswin_reduce_jobs).  tile_m: 64 or 128. */
+int pswin_gemm_nt_partial_rows(long long M, int tile_m);
+int pswin_gemm_nt_gelu_bwd(const void* dy, const void* w_t, const void* pre, const float* bias, void* dpre, float* partial, long long M,
+                           int K, int N, int tile_m, void* stream);
 
 /* Streaming GEMM for the Linear layers of the high-resolution stages (qkv / proj / fc1 / fc2 of stage 0, HOT:287, 309,
  * 50-58; proj of stage 1):  y[M, N] = x[M, K] . W^T (+ bias), bf16 in / out, f32 accumulation, the whole weight resident

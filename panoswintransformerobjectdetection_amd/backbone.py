@@ -86,7 +86,12 @@ class Mlp(nn.Module):
             h = ops.fc1_gelu(x2, self.fc1.weight, self.fc1.bias, lp[0] if lp is not None else None)
             h = h.view(*x.shape[:-1], h.shape[-1])
         else:
-            h = ops.bias_gelu(_linear(x, self.fc1, cd, use_bias=False), self.fc1.bias)
+            y = _linear(x, self.fc1, cd, use_bias=False)
+            if cd == torch.bfloat16 and ops.FUSED_GELU_BWD:
+                # stages 1-3: bias + GELU + fc2 as one autograd node: its backward runs fc2's data gradient and the GELU
+                # backward in one kernel
+                return ops.bias_gelu_linear(y, self.fc1.bias, self.fc2)
+            h = ops.bias_gelu(y, self.fc1.bias)
         return _linear(h, self.fc2, cd, use_bias=False)
 
 

@@ -23,6 +23,7 @@
 //   * tiles are dealt to the XCDs in contiguous chunks (blockIdx % 8 = XCD under round-robin placement; speed only) with
 //     the column tile fastest, so the tiles that share an activation panel hit the same L2.
 #include "pswin_common.hpp"
+#include "pswin_gelu.hpp"
 
 using namespace pswin;
 
@@ -45,16 +46,42 @@ __device__ inline u32x4 pack_row8(f32x4 q0, f32x4 q1) {
     return u32x4{r0[0], r1[0], r0[1], r1[1]};
 }
 
+// the same exchange on f32 quads (whole-vector bit casts: hipcc folds per-element casts of vector lanes)
+__device__ inline void exchange_row8(f32x4& q0, f32x4& q1) {
+    const u32x4 a = __builtin_bit_cast(u32x4, q0), b = __builtin_bit_cast(u32x4, q1);
+    const auto r0 = __builtin_amdgcn_permlane16_swap(a[0], b[0], false, false);
+    const auto r1 = __builtin_amdgcn_permlane16_swap(a[1], b[1], false, false);
+    const auto r2 = __builtin_amdgcn_permlane16_swap(a[2], b[2], false, false);
+    const auto r3 = __builtin_amdgcn_permlane16_swap(a[3], b[3], false, false);
+    q0 = __builtin_bit_cast(f32x4, u32x4{r0[0], r1[0], r2[0], r3[0]});
+    q1 = __builtin_bit_cast(f32x4, u32x4{r0[1], r1[1], r2[1], r3[1]});
+}
+template <int CTRL>
+__device__ inline float dpp_add(float v) {
+    return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+__device__ inline float row16_sum(float v) {   // over the 16 lanes of a group (every lane gets the sum)
+    v = dpp_add<0xB1>(v);
+    v = dpp_add<0x4E>(v);
+    v = dpp_add<0x141>(v);
+    return dpp_add<0x140>(v);
+}
+
 typedef __attribute__((address_space(3))) void lds_void;
 __device__ inline void glds16(const void* gsrc, char* lds_wave_base) {
     // 16 bytes per lane: LDS destination = wave-uniform base + lane * 16
     __builtin_amdgcn_global_load_lds(gsrc, (lds_void*)lds_wave_base, 16, 0, 0);
 }
 
-template <int BM>
+// EPI 0: y = acc (+ bias).  EPI 1 (the data gradient of fc2 fused with the backward of bias + GELU, HOT:50-58): acc = dL/dh of
+// the tile, aux = the Mlp's pre-activation [M, N], bias = fc1's bias; y = acc * gelu'(aux + bias) and the per-column sums of y
+// over the tile's rows (the fc1 bias gradient) go to partial[tile_m][N] -- dL/dh never exists in HBM and the separate
+// bias + GELU backward pass (two reads and a write of [M, 4C]) is gone.
+template <int BM, int EPI>
 __global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_kernel(const unsigned short* __restrict__ X, const unsigned short* __restrict__ W,
                                                                  const float* __restrict__ bias, unsigned short* __restrict__ Y,
-                                                                 int M, int N, int K, int tiles_m, int tiles_n) {
+                                                                 int M, int N, int K, int tiles_m, int tiles_n,
+                                                                 const unsigned short* __restrict__ aux, float* __restrict__ partial) {
     constexpr int RT = BM / 32;                       // 16-row tiles per wave (waves: 2 along M x 2 along N)
     constexpr int CT = BN / 32;                       // 16-column tiles per wave: 6
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
@@ -140,35 +167,88 @@ __global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_kernel(const unsigned s
     // acc[i][j][e] = Y[row m0 + wm * BM/2 + 16 i + c][column n0 + wn * 96 + 16 j + 4 g + e]
     const rsrc_t ys = __builtin_amdgcn_make_buffer_rsrc(Y, 0, (int)((size_t)M * N * 2), 0x00020000);
     const int d0 = 8 * (g >> 1) + 16 * (g & 1);
+    if constexpr (EPI == 0) {
 #pragma unroll
-    for (int i = 0; i < RT; ++i) {
-        const unsigned row = (unsigned)(m0 + wm * (BM / 2) + 16 * i + c);
-        const unsigned base = row < (unsigned)M ? row * (unsigned)(N * 2) + (unsigned)((n0 + wn * (BN / 2) + d0) * 2) : 0xFFFFFF00u;
+        for (int i = 0; i < RT; ++i) {
+            const unsigned row = (unsigned)(m0 + wm * (BM / 2) + 16 * i + c);
+            const unsigned base = row < (unsigned)M ? row * (unsigned)(N * 2) + (unsigned)((n0 + wn * (BN / 2) + d0) * 2) : 0xFFFFFF00u;
+#pragma unroll
+            for (int jp = 0; jp < CT / 2; ++jp) {
+                f32x4 q0 = acc[i][2 * jp], q1 = acc[i][2 * jp + 1];
+                if (bias) {
+                    q0 += *reinterpret_cast<const f32x4*>(bias + n0 + wn * (BN / 2) + 32 * jp + 4 * g);
+                    q1 += *reinterpret_cast<const f32x4*>(bias + n0 + wn * (BN / 2) + 32 * jp + 16 + 4 * g);
+                }
+                const unsigned off = base == 0xFFFFFF00u ? base : base + 64u * jp;
+                __builtin_amdgcn_raw_buffer_store_b128(pack_row8(q0, q1), ys, off, 0, 0);
+            }
+        }
+    } else {
+        const rsrc_t as = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(aux), 0, (int)((size_t)M * N * 2), 0x00020000);
+        float csum[CT / 2][8];                        // column sums over this wave's rows: columns 32 jp + d0 + j of its 96
+#pragma unroll
+        for (int jp = 0; jp < CT / 2; ++jp)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) csum[jp][j] = 0.f;
 #pragma unroll
         for (int jp = 0; jp < CT / 2; ++jp) {
-            f32x4 q0 = acc[i][2 * jp], q1 = acc[i][2 * jp + 1];
+            const int col8 = n0 + wn * (BN / 2) + 32 * jp + d0;
+            f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
             if (bias) {
-                q0 += *reinterpret_cast<const f32x4*>(bias + n0 + wn * (BN / 2) + 32 * jp + 4 * g);
-                q1 += *reinterpret_cast<const f32x4*>(bias + n0 + wn * (BN / 2) + 32 * jp + 16 + 4 * g);
+                b0 = *reinterpret_cast<const f32x4*>(bias + col8);
+                b1 = *reinterpret_cast<const f32x4*>(bias + col8 + 4);
             }
-            const unsigned off = base == 0xFFFFFF00u ? base : base + 64u * jp;
-            __builtin_amdgcn_raw_buffer_store_b128(pack_row8(q0, q1), ys, off, 0, 0);
+#pragma unroll
+            for (int i = 0; i < RT; ++i) {
+                const unsigned row = (unsigned)(m0 + wm * (BM / 2) + 16 * i + c);
+                const bool ok = row < (unsigned)M;
+                const unsigned off = ok ? row * (unsigned)(N * 2) + (unsigned)(col8 * 2) : 0xFFFFFF00u;
+                f32x4 q0 = acc[i][2 * jp], q1 = acc[i][2 * jp + 1];
+                exchange_row8(q0, q1);                // 8 consecutive columns col8 .. col8 + 7 of this lane's row
+                const u32x4 yv = __builtin_amdgcn_raw_buffer_load_b128(as, off, 0, 0);
+                float v[8];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const gelu_f32x2 pre = {__builtin_bit_cast(float, yv[d] << 16) + (d < 2 ? b0[2 * d] : b1[2 * d - 4]),
+                                            __builtin_bit_cast(float, yv[d] & 0xffff0000u) + (d < 2 ? b0[2 * d + 1] : b1[2 * d - 3])};
+                    const gelu_f32x2 gg = gelu_grad_f2(pre);
+                    v[2 * d] = (d < 2 ? q0[2 * d] : q1[2 * d - 4]) * gg[0];
+                    v[2 * d + 1] = (d < 2 ? q0[2 * d + 1] : q1[2 * d - 3]) * gg[1];
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{pk2(v[0], v[1]), pk2(v[2], v[3]), pk2(v[4], v[5]), pk2(v[6], v[7])}, ys, off, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) csum[jp][j] += row16_sum(ok ? v[j] : 0.f);      // rows past M: clamped duplicates, not counted
+            }
+        }
+        __syncthreads();                              // every wave is done with the operand stages: reuse them for the column sums
+        float* cs = reinterpret_cast<float*>(smem);   // [4 waves][96]
+        if (c == 0) {
+#pragma unroll
+            for (int jp = 0; jp < CT / 2; ++jp)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) cs[wave * (BN / 2) + 32 * jp + d0 + j] = csum[jp][j];
+        }
+        __syncthreads();
+        if (tid < BN) {
+            const int wn2 = tid / (BN / 2), cc = tid - wn2 * (BN / 2);
+            partial[(size_t)tm * N + n0 + tid] = cs[wn2 * (BN / 2) + cc] + cs[(2 + wn2) * (BN / 2) + cc];     // waves (wm = 0, 1; wn2)
         }
     }
 }
 
-template <int BM>
-int launch_nt(const void* x, const void* w, const float* bias, void* y, int M, int N, int K, hipStream_t st) {
+template <int BM, int EPI>
+int launch_nt(const void* x, const void* w, const float* bias, void* y, int M, int N, int K, hipStream_t st, const void* aux = nullptr,
+              float* partial = nullptr) {
     constexpr size_t lds = 2 * (size_t)(BM + BN) * BK * 2;
     static bool configured = false;
     if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         configured = true;
     }
     const int tiles_m = (M + BM - 1) / BM, tiles_n = N / BN;
-    hipLaunchKernelGGL((gemm_nt_kernel<BM>), dim3(tiles_m * tiles_n), dim3(NT_THREADS), lds, st,
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, EPI>), dim3(tiles_m * tiles_n), dim3(NT_THREADS), lds, st,
                        reinterpret_cast<const unsigned short*>(x), reinterpret_cast<const unsigned short*>(w), bias,
-                       reinterpret_cast<unsigned short*>(y), M, N, K, tiles_m, tiles_n);
+                       reinterpret_cast<unsigned short*>(y), M, N, K, tiles_m, tiles_n, reinterpret_cast<const unsigned short*>(aux), partial);
     PSWIN_LAUNCH_RET();
 }
 
@@ -186,8 +266,20 @@ int pswin_gemm_nt(const void* x, const void* w, const float* bias, void* y, long
     PSWIN_CHECK_ARG(aligned16(x) && aligned16(w) && aligned16(y) && aligned16(bias));
     const int m = (int)M;
     if (tile_m == 0) tile_m = ((long long)((m + 127) / 128) * (N / BN) >= 512) ? 128 : 64;
-    if (tile_m == 128) return launch_nt<128>(x, w, bias, y, m, N, K, (hipStream_t)stream);
-    return launch_nt<64>(x, w, bias, y, m, N, K, (hipStream_t)stream);
+    if (tile_m == 128) return launch_nt<128, 0>(x, w, bias, y, m, N, K, (hipStream_t)stream);
+    return launch_nt<64, 0>(x, w, bias, y, m, N, K, (hipStream_t)stream);
+}
+
+int pswin_gemm_nt_partial_rows(long long M, int tile_m) {
+    return (M > 0 && (tile_m == 64 || tile_m == 128)) ? (int)((M + tile_m - 1) / tile_m) : PSWIN_ERR_ARG;
+}
+
+int pswin_gemm_nt_gelu_bwd(const void* dy, const void* w_t, const void* pre, const float* bias, void* dpre, float* partial, long long M,
+                           int K, int N, int tile_m, void* stream) {
+    PSWIN_CHECK_ARG(dy && w_t && pre && dpre && partial && pswin_gemm_nt_supported(M, K, N) && (tile_m == 64 || tile_m == 128));
+    PSWIN_CHECK_ARG(aligned16(dy) && aligned16(w_t) && aligned16(pre) && aligned16(dpre) && aligned16(bias) && aligned16(partial));
+    if (tile_m == 128) return launch_nt<128, 1>(dy, w_t, bias, dpre, (int)M, N, K, (hipStream_t)stream, pre, partial);
+    return launch_nt<64, 1>(dy, w_t, bias, dpre, (int)M, N, K, (hipStream_t)stream, pre, partial);
 }
 
 }  // extern "C"

@@ -23,6 +23,8 @@ GEMM_NT = os.environ.get("PSWIN_GEMM_NT", "1") != "0"
 # stage 1-3 shapes (profiles/r02_gemm_tn_split_sweep.txt), but its f32 partial slabs cost the step what the kernel gains
 # (same-box A/B, profiles/r02_ab_gemm.txt): opt-in
 GEMM_TN = os.environ.get("PSWIN_GEMM_TN", "0") != "0"
+# fc2's data gradient + the backward of fc1's bias + GELU in one kernel (pswin_gemm_nt_gelu_bwd); PSWIN_FUSED_GELU_BWD=0: two kernels
+FUSED_GELU_BWD = os.environ.get("PSWIN_FUSED_GELU_BWD", "1") != "0"
 
 
 def _dev_key(device):
@@ -896,6 +898,71 @@ class _BiasGelu(torch.autograd.Function):
         db = sum_rows(ws, lib.pswin_bias_gelu_partial_rows(M, N, dtype_code(y)), N, owners=(ctx.bias,)) \
             if b is not None else None
         return dy, db
+
+
+class _BiasGeluLinear(torch.autograd.Function):
+    """out = gelu(y + b1) @ W2^T: fc1's bias + nn.GELU followed by fc2 WITHOUT its bias (HOT:50-58; the caller adds fc2's bias with
+    the residual).  One function so that the backward pass can run the data gradient of fc2 and the backward of bias + GELU
+    in ONE kernel (pswin_gemm_nt_gelu_bwd): dL/dh [M, 4C] is never written or re-read, and the fc1 bias gradient comes
+    out of the same epilogue as per-tile column sums."""
+
+    @staticmethod
+    def forward(ctx, y, b1, w2, w2_lp, w2_lp_t):
+        y = y.contiguous()
+        shp = y.shape
+        y2 = y.view(-1, shp[-1])
+        M, N = y2.shape
+        h = torch.empty_like(y2)
+        b = None if b1 is None else b1.detach().float().contiguous()
+        call("pswin_bias_gelu_fwd", y2, ptr(y2), dtype_code(y2), ptr(b), ptr(h), M, N, algo_bytes=2 * y2.numel() * y2.element_size())
+        wb = w2_lp if w2_lp is not None else w2.to(y.dtype)
+        C = wb.shape[0]
+        tile = gemm_nt_tile(M, N, C)
+        if tile:
+            out = gemm_nt(h, wb, None, tile)
+        else:
+            with _lib.timed("lib_gemm_fwd", 2 * (M * N + M * C + N * C), 2 * M * N * C):
+                out = F.linear(h, wb)
+        ctx.save_for_backward(y2, b, h, wb, w2_lp_t)
+        ctx.params = (b1, w2)
+        return out.view(*shp[:-1], C)
+
+    @staticmethod
+    def backward(ctx, dout):
+        y2, b, h, wb, wbt = ctx.saved_tensors
+        b1, w2 = ctx.params
+        M, N = y2.shape
+        C = wb.shape[0]
+        dout = dout.reshape(M, C).contiguous()
+        lib = _lib.load()
+        tile = 0
+        if wbt is not None and GEMM_NT and lib.pswin_gemm_nt_supported(M, C, N):
+            tile = gemm_nt_tile(M, C, N) or 64        # (the narrow stage-3 case the plain rule leaves to the library: fused it wins)
+        if tile:
+            dpre = torch.empty_like(y2)
+            rows = lib.pswin_gemm_nt_partial_rows(M, tile)
+            ws = torch.empty(rows, N, dtype=torch.float32, device=y2.device)
+            call("pswin_gemm_nt_gelu_bwd", y2, ptr(dout), ptr(wbt), ptr(y2), ptr(b), ptr(dpre), ptr(ws), M, C, N, tile,
+                 algo_bytes=2 * (M * C + 2 * M * N + N * C), algo_flops=2 * M * N * C)
+            db = sum_rows(ws, rows, N, owners=(b1,)) if b is not None else None
+        else:
+            with _lib.timed("lib_gemm_dgrad", 2 * (M * N + M * C + N * C), 2 * M * N * C):
+                dh = dout @ wb
+            dpre = torch.empty_like(y2)
+            ws = torch.empty(lib.pswin_bias_gelu_workspace(M, N), dtype=torch.float32, device=y2.device)
+            call("pswin_bias_gelu_bwd", y2, ptr(dh), ptr(y2), dtype_code(y2), ptr(b), ptr(dpre), None, ptr(ws), M, N,
+                 algo_bytes=3 * y2.numel() * y2.element_size())
+            db = sum_rows(ws, lib.pswin_bias_gelu_partial_rows(M, N, dtype_code(y2)), N, owners=(b1,)) if b is not None else None
+        _, dw, _ = linear_backward(h, wb, dout, w2, None, None, False)
+        return dpre.view_as(y2), db, dw, None, None
+
+
+def bias_gelu_linear(y, bias1, lin2):
+    """lin2(gelu(y + bias1)) without lin2's bias (bf16 rows): see _BiasGeluLinear."""
+    lp = lin2.__dict__.get("_lowp")
+    out = _BiasGeluLinear.apply(y.reshape(-1, y.shape[-1]), bias1, lin2.weight, lp[0] if lp is not None else None,
+                                lin2.__dict__.get("_lowp_t"))
+    return out.view(*y.shape[:-1], lin2.weight.shape[0])
 
 
 def bias_gelu(y, bias):

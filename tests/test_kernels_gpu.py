@@ -791,3 +791,47 @@ def test_gemm_tn_against_torch(ops, M, N, K, splits):
     ref = dy.float().t() @ x.float()
     assert torch.allclose(got, ref, rtol=2e-3, atol=2e-3 * float(ref.abs().max())), (got - ref).abs().max()
     assert lib.pswin_gemm_tn_supported(M, 576, 192) == 0 and lib.pswin_gemm_tn_supported(M, N + 64, K) == 0
+
+
+@pytest.mark.parametrize("M,C,tile", [(16384, 384, 128), (4096, 768, 64), (333, 192, 64), (19600, 384, 128)])
+def test_gelu_backward_fused_into_the_fc2_data_gradient(ops, M, C, tile):
+    """pswin_gemm_nt_gelu_bwd: (dy . W2) * gelu'(pre + b1) and the per-tile column sums, against fp32 torch on the same bf16
+    operands (ragged M: rows past M must not enter the column sums); then the autograd node ops.bias_gelu_linear against the
+    two-kernel chain bias_gelu + linear."""
+    import torch.nn as nn
+    from panoswintransformerobjectdetection_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(M + C)
+    N = 4 * C
+    dy = torch.randn(M, C, device=DEV).to(torch.bfloat16)
+    w2 = (torch.randn(C, N, device=DEV) / math.sqrt(N)).to(torch.bfloat16)              # fc2.weight [C, 4C]
+    pre = torch.randn(M, N, device=DEV).to(torch.bfloat16)
+    b1 = torch.randn(N, device=DEV) * 0.1
+    wt = w2.t().contiguous()                                                            # [4C, C]: the kernel's "weight"
+    rows = lib.pswin_gemm_nt_partial_rows(M, tile)
+    dpre = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    ws = torch.empty(rows, N, dtype=torch.float32, device=DEV)
+    ops.call("pswin_gemm_nt_gelu_bwd", dy, ops.ptr(dy), ops.ptr(wt), ops.ptr(pre), ops.ptr(b1), ops.ptr(dpre), ops.ptr(ws), M, C, N, tile)
+    z = (pre.float() + b1).requires_grad_(True)
+    F.gelu(z).backward(dy.float() @ w2.float())
+    ref = z.grad
+    assert torch.allclose(dpre.float(), ref, rtol=2e-2, atol=2e-2)
+    assert torch.allclose(ws.sum(0), ref.sum(0), rtol=1e-2, atol=2e-2 * float(ref.sum(0).abs().max()))
+    # the autograd node against the two-kernel chain
+    fc2 = nn.Linear(N, C).to(DEV)
+    with torch.no_grad():
+        fc2.weight.copy_(w2.float())
+    fc2.__dict__["_lowp"] = (w2, None)
+    fc2.__dict__["_lowp_t"] = wt
+    bias1 = nn.Parameter(b1.clone())
+    g = torch.randn(M, C, device=DEV).to(torch.bfloat16)
+
+    def run(fused):
+        y = pre.clone().requires_grad_(True)
+        bias1.grad = fc2.weight.grad = None
+        out = ops.bias_gelu_linear(y, bias1, fc2) if fused else ops.linear(ops.bias_gelu(y, bias1), fc2, torch.bfloat16, use_bias=False)
+        out.backward(g)
+        return out.detach().float(), y.grad.float(), bias1.grad.clone(), fc2.weight.grad.clone()
+    a, b = run(True), run(False)
+    for u, v in zip(a, b):
+        assert torch.allclose(u, v, rtol=2e-2, atol=2e-2 * float(v.abs().max())), (u - v).abs().max()
