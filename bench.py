@@ -58,7 +58,7 @@ TCFG = dict(embed_dim=96, depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24], window_
             drop_path_rate=0.2, pano_mode=True)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md; ~6.3 TB/s achievable)
 MFMA_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak (MI355X_MICROARCH.md)
-TIMED = ("pswin_win_attn_fused_fwd", "pswin_attn_fwd", "pswin_attn_bwd", "pswin_window_gather", "pswin_window_scatter_add",
+TIMED = ("pswin_win_attn_fused_fwd", "pswin_attn_fwd", "pswin_attn_bwd", "pswin_attn_bwd_ex", "pswin_window_gather", "pswin_window_scatter_add",
          "pswin_scatter_add_ln_fwd", "pswin_ln_gather_fwd", "pswin_ln_gather_bwd", "pswin_bias_gelu_fwd", "pswin_bias_gelu_bwd",
          "pswin_gemm_skinny", "pswin_gemm_nt", "pswin_gemm_nt_gelu_bwd", "pswin_gemm_tn", "pswin_fc1_gelu_fwd", "pswin_fc1_gelu_bwd", "pswin_stem_conv2_fwd", "pswin_stem_conv3_fwd",
          "pswin_stem_conv3_bwd_stats", "pswin_stem_conv3_bwd_data", "pswin_stem_conv3_wgrad", "pswin_stem_conv2_wgrad",
@@ -357,7 +357,7 @@ def main():
             pass
         roofline["traffic"], roofline["traffic_source"] = traffic, tnote
         # the window-attention kernels (what BASELINE's metric string and the north star grade), whichever is dominant
-        roofline["window_attention"] = {n: roof(n) for n in ("pswin_win_attn_fused_fwd", "pswin_attn_fwd", "pswin_attn_bwd") if n in stats}
+        roofline["window_attention"] = {n: roof(n) for n in ("pswin_win_attn_fused_fwd", "pswin_attn_fwd", "pswin_attn_bwd_ex") if n in stats}
         try:
             with open(os.path.join(ROOT, MFMA_BUSY_FILE)) as f:
                 mb = json.load(f)

@@ -429,8 +429,9 @@ int pswin_attn_suggest_chunks(int n_windows, int n_bias_windows, int heads, int 
  * are resident in LDS as MFMA operand fragments and every product of a window runs out of registers
  * (csrc/pswin_fused.hip).  w_qkv: [3C, C], w_proj: [C, C] (nn.Linear layout), b_qkv: f32 [3C] or NULL; dist / mask tiles,
  * tables, n_bias_windows and scale as pswin_attn_fwd (forward tiles, not transposed).
- * Training: pass qkv_out [n*49, 3C], att_out [n*49, C] (the attention output before proj) and lse_out f32 [n, heads, 64]
- * (all three or none): exactly the tensors pswin_attn_bwd and the weight-gradient GEMMs of the unfused path read.
+ * Training: pass qkv_out (bf16 [n, heads, 3, 49, 32]: q, k, v of a head as contiguous blocks, the packing pswin_attn_bwd_ex
+ * reads), att_out [n*49, C] (the attention output before proj, row-major: the proj weight-gradient GEMM reads it) and
+ * lse_out f32 [n, heads, 64] (all three or none).
  * Specialised for C = 96, heads = 3, PSWIN_BF16 (PanoSwin-T / -S stage 0); pswin_win_attn_fused_supported says so,
  * anything else returns PSWIN_ERR_UNSUPPORTED.  Rounding points are those of the unfused bf16 path (qkv and the attention
  * output rounded to bf16, f32 scores / softmax / accumulation). */
@@ -449,6 +450,16 @@ int pswin_attn_bwd(const void* q, const void* k, const void* v, int ld_qkv, cons
                    const float* alpha, const float* beta, const float* mask_tiles_t, int n_mask, const void* dout,
                    int ld_out, const float* lse, void* dq, void* dk, void* dv, int ld_dqkv, float* dscore_sum,
                    int n_chunks, int n_windows, int n_bias_windows, int heads, float scale, int dtype, void* stream);
+/* The same with q / k / v in any packing: window w, head h starts w * qkv_window_stride + h * qkv_head_stride elements behind the
+ * q / k / v pointer, token rows ld_qkv elements apart.  pswin_win_attn_fused_fwd saves q, k, v as contiguous [49][32] blocks
+ * ([n][heads][3][49][32]: ld_qkv = 32, head stride 3 * 49 * 32, window stride heads * 3 * 49 * 32; k = q + 49 * 32 elements,
+ * v = q + 2 * 49 * 32), which it can write -- and this kernel read -- as whole 1 KB runs instead of 64-byte row segments. */
+int pswin_attn_bwd_ex(const void* q, const void* k, const void* v, int ld_qkv, long long qkv_window_stride, int qkv_head_stride,
+                      const float* dist_tiles_t, int n_dist, const float* alpha, const float* beta, const float* mask_tiles_t,
+                      int n_mask, const void* dout, int ld_out, const float* lse, void* dq, void* dk, void* dv, int ld_dqkv,
+                      float* dscore_sum, int n_chunks, int n_windows, int n_bias_windows, int heads, float scale, int dtype,
+                      void* stream);
+
 
 /* Table gradients (adjoint of the bias w.r.t. alpha, beta), in a fixed summation order:
  *   dbeta[t][h] = sum over tiles and (i,j) with idx(i,j) = t of g ;  dalpha[t][h] = the same sum of g * dist(i,j).

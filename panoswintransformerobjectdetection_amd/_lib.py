@@ -93,6 +93,8 @@ _PROTOTYPES = {
     "pswin_attn_suggest_chunks": [_i, _i, _i, _i],
     "pswin_attn_bwd": [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp,
                        _i, _i, _i, _i, _f, _i, _vp],
+    "pswin_attn_bwd_ex": [_vp, _vp, _vp, _i, ctypes.c_longlong, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp,
+                          _i, _i, _i, _i, _f, _i, _vp],
     "pswin_attn_table_grads_workspace": [_i],
     "pswin_attn_table_grads": [_vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp],
 }

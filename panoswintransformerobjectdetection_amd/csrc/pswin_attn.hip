@@ -51,6 +51,10 @@ struct AttnArgs {
     float* dtab;            // bwd: [n_items][64 j][64 i] sums of dS over the item's images, or null
     int n_dist, n_mask;
     int ld_qkv, ld_out, ld_dqkv;
+    // (backward) where window w, head h of q / k / v starts, in elements from the q / k / v pointer: w * qkv_win_stride +
+    // h * qkv_head_stride.  Row-major [n*49, ld_qkv] buffers: 49 * ld_qkv and 32; pswin_attn_bwd_ex takes any other packing.
+    long long qkv_win_stride;
+    int qkv_head_stride;
     int nb, heads, reps_per_chunk, n_items;
     float scale;
 };
@@ -264,8 +268,8 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_kernel(AttnArgs a) {
         dx_off[tt] = (unsigned)((16 * tt + c) * a.ld_dqkv) * ES<DT>;
     }
     auto load_tiles = [&](int r, Tiles4<DT>& t) {
-        const size_t row0 = ((size_t)(chunk * a.reps_per_chunk + r) * a.nb + wb) * TOK;
-        const size_t head0 = (row0 * (size_t)a.ld_qkv + h * HD) * ES<DT>;
+        const size_t win_ = (size_t)(chunk * a.reps_per_chunk + r) * a.nb + wb, row0 = win_ * TOK;
+        const size_t head0 = (win_ * (size_t)a.qkv_win_stride + (size_t)h * a.qkv_head_stride) * ES<DT>;
         const rsrc_t qb = window_rsrc<DT>(a.q, head0, a.ld_qkv);
         const rsrc_t kb = window_rsrc<DT>(a.k, head0, a.ld_qkv);
         const rsrc_t vb = window_rsrc<DT>(a.v, head0, a.ld_qkv);
@@ -504,8 +508,8 @@ __global__ __launch_bounds__(128, 2) void attn_bwd_pair_kernel(AttnArgs a) {
         dq_off[tt] = (unsigned)((16 * (2 * w + tt) + c) * a.ld_dqkv) * 2u;
     }
     auto load_ops = [&](int r, Ops& t) {
-        const size_t row0 = ((size_t)(chunk * a.reps_per_chunk + r) * a.nb + wb) * TOK;
-        const size_t head0 = (row0 * (size_t)a.ld_qkv + h * HD) * 2;
+        const size_t win_ = (size_t)(chunk * a.reps_per_chunk + r) * a.nb + wb, row0 = win_ * TOK;
+        const size_t head0 = (win_ * (size_t)a.qkv_win_stride + (size_t)h * a.qkv_head_stride) * 2;
         const rsrc_t qb = window_rsrc<DT>(a.q, head0, a.ld_qkv);
         const rsrc_t kb = window_rsrc<DT>(a.k, head0, a.ld_qkv);
         const rsrc_t vb = window_rsrc<DT>(a.v, head0, a.ld_qkv);
@@ -886,14 +890,18 @@ extern "C" int pswin_attn_table_grads_workspace(int heads) {
     return heads > 0 ? (DTAB_BLOCKS + 1) * dtab_ld(heads) : PSWIN_ERR_ARG;   // block partial rows + their sum
 }
 
-extern "C" int pswin_attn_bwd(const void* q, const void* k, const void* v, int ld_qkv, const float* dist_t, int n_dist,
-                              const float* alpha, const float* beta, const float* mask_t, int n_mask,
-                              const void* dout, int ld_out, const float* lse, void* dq, void* dk, void* dv,
-                              int ld_dqkv, float* dscore_sum, int n_chunks, int n_windows, int n_bias_windows,
-                              int heads, float scale, int dtype, void* stream) {
-    int rc = check_attn_common(q, k, v, ld_qkv, n_windows, n_bias_windows, heads, dtype, dist_t, n_dist, alpha, beta,
-                               mask_t, n_mask);
-    if (rc) return rc;
+extern "C" int pswin_attn_bwd_ex(const void* q, const void* k, const void* v, int ld_qkv, long long qkv_window_stride,
+                                 int qkv_head_stride, const float* dist_t, int n_dist, const float* alpha, const float* beta,
+                                 const float* mask_t, int n_mask, const void* dout, int ld_out, const float* lse, void* dq, void* dk,
+                                 void* dv, int ld_dqkv, float* dscore_sum, int n_chunks, int n_windows, int n_bias_windows,
+                                 int heads, float scale, int dtype, void* stream) {
+    PSWIN_CHECK_ARG(q && k && v && beta && valid_dtype(dtype) && n_windows > 0 && n_bias_windows > 0 && heads > 0);
+    PSWIN_CHECK_ARG(n_windows % n_bias_windows == 0 && ld_qkv >= HD && ld_qkv % 8 == 0 && qkv_head_stride % 8 == 0 && qkv_window_stride % 8 == 0);
+    PSWIN_CHECK_ARG(qkv_head_stride >= HD && qkv_window_stride >= (long long)(TOK - 1) * ld_qkv + HD);
+    PSWIN_CHECK_ARG(aligned16(q) && aligned16(k) && aligned16(v) && aligned16(dist_t) && aligned16(mask_t));
+    PSWIN_CHECK_ARG((long long)n_windows * qkv_window_stride < (1ll << 40));
+    PSWIN_CHECK_ARG(!dist_t || (alpha && n_dist > 0 && n_bias_windows % n_dist == 0));
+    PSWIN_CHECK_ARG(!mask_t || (n_mask > 0 && n_bias_windows % n_mask == 0));
     PSWIN_CHECK_ARG(dout && lse && dq && dk && dv);
     PSWIN_CHECK_ARG(aligned16(dout) && aligned16(dq) && aligned16(dk) && aligned16(dv) && aligned16(lse));
     PSWIN_CHECK_ARG(ld_out >= heads * HD && ld_out % 8 == 0 && ld_dqkv >= heads * HD && ld_dqkv % 8 == 0);
@@ -906,6 +914,7 @@ extern "C" int pswin_attn_bwd(const void* q, const void* k, const void* v, int l
     a.dout = dout; a.lse = const_cast<float*>(lse);
     a.dq = dq; a.dk = dk; a.dv = dv; a.dtab = dscore_sum;
     a.ld_qkv = ld_qkv; a.ld_out = ld_out; a.ld_dqkv = ld_dqkv;
+    a.qkv_win_stride = qkv_window_stride; a.qkv_head_stride = qkv_head_stride;
     a.nb = n_bias_windows; a.heads = heads; a.reps_per_chunk = reps / n_chunks;
     a.n_items = n_chunks * n_bias_windows * heads;
     a.scale = scale;
@@ -917,6 +926,16 @@ extern "C" int pswin_attn_bwd(const void* q, const void* k, const void* v, int l
                            (hipStream_t)stream, a);
     }
     PSWIN_LAUNCH_RET();
+}
+
+extern "C" int pswin_attn_bwd(const void* q, const void* k, const void* v, int ld_qkv, const float* dist_t, int n_dist,
+                              const float* alpha, const float* beta, const float* mask_t, int n_mask,
+                              const void* dout, int ld_out, const float* lse, void* dq, void* dk, void* dv,
+                              int ld_dqkv, float* dscore_sum, int n_chunks, int n_windows, int n_bias_windows,
+                              int heads, float scale, int dtype, void* stream) {
+    PSWIN_CHECK_ARG(ld_qkv >= heads * HD);
+    return pswin_attn_bwd_ex(q, k, v, ld_qkv, (long long)TOK * ld_qkv, HD, dist_t, n_dist, alpha, beta, mask_t, n_mask, dout, ld_out, lse,
+                             dq, dk, dv, ld_dqkv, dscore_sum, n_chunks, n_windows, n_bias_windows, heads, scale, dtype, stream);
 }
 
 extern "C" int pswin_attn_table_grads_batch(const pswin_table_grad_job* jobs, int n_jobs, int stages, void* stream) {

@@ -59,7 +59,7 @@ struct FusedArgs {
     const float* alpha;     // [169][3]
     const float* beta;      // [169][3]
     void* y;                // [n*49][96] bf16: attention output @ Wproj^T (no bias)
-    void* qkv;              // SAVE: [n*49][288] bf16
+    void* qkv;              // SAVE: [n][3 heads][q | k | v][49][32] bf16
     void* att;              // SAVE: [n*49][96] bf16
     float* lse;             // SAVE: [n][3][64] f32
     int n_dist, n_mask, nb, reps;
@@ -239,14 +239,22 @@ __global__ __launch_bounds__(FTHREADS, 2) void win_fused_fwd_kernel(FusedArgs a)
                     // pipe has the room, an LDS transpose of the other orientation costs VALU / LDS issue slots instead)
                     u32x4 vf[4];
                     gemm_T(wA, bA, vf);
-                    const rsrc_t qs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.qkv) + row0 * (3 * FC * 2) + h * HD * 2, 0,
-                                                                        (TOK - 1) * 3 * FC * 2 + (2 * FC + HD) * 2, 0x00020000);
+                    // q, k, v of (window, head) as three contiguous [49][32] blocks ([n][heads][3][49][32], the packing
+                    // pswin_attn_bwd_ex reads): a store instruction then writes ONE 1 KB run (16 tokens x 64 B) instead of 16
+                    // 64-byte segments 576 B apart; tokens >= 49 fall outside the resource and are dropped
+                    constexpr int BLK = TOK * HD * 2;
+                    const rsrc_t qs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.qkv) + (win * FH + h) * (size_t)(3 * BLK), 0,
+                                                                        BLK, 0x00020000);
+                    const rsrc_t ks = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.qkv) + (win * FH + h) * (size_t)(3 * BLK) + BLK, 0,
+                                                                        BLK, 0x00020000);
+                    const rsrc_t vs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.qkv) + (win * FH + h) * (size_t)(3 * BLK) + 2 * BLK,
+                                                                        0, BLK, 0x00020000);
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
-                        const unsigned ro = (unsigned)((16 * t + c) * (3 * FC * 2) + d0 * 2);
+                        const unsigned ro = (unsigned)((16 * t + c) * (HD * 2) + d0 * 2);
                         __builtin_amdgcn_raw_buffer_store_b128(row8(qf[t]), qs, ro, 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b128(row8(kf[t]), qs, ro + FC * 2, 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b128(row8(vf[t]), qs, ro + 2 * FC * 2, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(row8(kf[t]), ks, ro, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(row8(vf[t]), vs, ro, 0, 0);
                     }
                 }
                 {

@@ -1089,16 +1089,27 @@ class _WindowAttention(torch.autograd.Function):
         return dx, dk, dv, dalpha, dbeta, None, None, None, None, None, None
 
 
-def attention_backward(x, k, v, lse, alpha, beta, dist, mask, dout, heads, scale, nb, chunks, need_tables, owners):
+def attention_backward(x, k, v, lse, alpha, beta, dist, mask, dout, heads, scale, nb, chunks, need_tables, owners, packed=False):
     """Backward of the attention core (pswin_attn_bwd + the table-gradient kernels): x = fused [rows, 3C] qkv (k = v =
-    None) or q with separate k, v.  Returns (dx, dk, dv, dalpha, dbeta); owners = the (alpha, beta) parameters."""
+    None) or q with separate k, v; packed=True: x = [n, heads, 3, 49, 32] (what the fused forward kernel saves), the
+    gradient still comes back as one row-major [rows, 3C] tensor.  Returns (dx, dk, dv, dalpha, dbeta); owners = the
+    (alpha, beta) parameters."""
     import ctypes
     C = heads * _lib.HEAD_DIM
-    n = x.shape[0] // WTOK
+    n = x.shape[0] if packed else x.shape[0] // WTOK
     fused = k is None
     dout = dout.contiguous()
     es = x.element_size()
-    if fused:
+    ld_in, win_stride, head_stride = None, None, _lib.HEAD_DIM
+    if packed:
+        dx = torch.empty(n * WTOK, 3 * C, dtype=x.dtype, device=x.device)
+        ld = 3 * C
+        blk = WTOK * _lib.HEAD_DIM
+        qp, kp, vp = x.data_ptr(), x.data_ptr() + blk * es, x.data_ptr() + 2 * blk * es
+        dqp, dkp, dvp = dx.data_ptr(), dx.data_ptr() + C * es, dx.data_ptr() + 2 * C * es
+        dk = dv = None
+        ld_in, win_stride, head_stride = _lib.HEAD_DIM, heads * 3 * blk, 3 * blk
+    elif fused:
         dx = torch.empty_like(x)
         ld = 3 * C
         qp, kp, vp = x.data_ptr(), x.data_ptr() + C * es, x.data_ptr() + 2 * C * es
@@ -1114,7 +1125,9 @@ def attention_backward(x, k, v, lse, alpha, beta, dist, mask, dout, heads, scale
     dalpha = dbeta = gsum = None
     if need_tables:
         gsum = torch.empty(chunks * nb, heads, WPAD, WPAD, dtype=torch.float32, device=x.device)
-    call("pswin_attn_bwd", x, ctypes.c_void_p(qp), ctypes.c_void_p(kp), ctypes.c_void_p(vp), ld,
+    ld_in = ld if ld_in is None else ld_in
+    win_stride = WTOK * ld_in if win_stride is None else win_stride
+    call("pswin_attn_bwd_ex", x, ctypes.c_void_p(qp), ctypes.c_void_p(kp), ctypes.c_void_p(vp), ld_in, win_stride, head_stride,
          ptr(None if dist is None else dist.bwd), 0 if dist is None else dist.n, ptr(alpha), ptr(beta),
          ptr(None if mask is None else mask.bwd), 0 if mask is None else mask.n, ptr(dout), C, ptr(lse),
          ctypes.c_void_p(dqp), ctypes.c_void_p(dkp), ctypes.c_void_p(dvp), ld, ptr(gsum),
@@ -1179,7 +1192,7 @@ class _WindowAttentionFused(torch.autograd.Function):
         y = torch.empty_like(x)
         qkv = att = lse = None
         if save:
-            qkv = torch.empty(rows, 3 * C, dtype=x.dtype, device=x.device)
+            qkv = torch.empty(n, heads, 3, WTOK, _lib.HEAD_DIM, dtype=x.dtype, device=x.device)     # packed blocks (pswin_attn_bwd_ex)
             att = torch.empty_like(x)
             lse = torch.empty(n, heads, WPAD, dtype=torch.float32, device=x.device)
         flops = n * (2 * WTOK * C * 3 * C + heads * 4 * WTOK * WTOK * _lib.HEAD_DIM + 2 * WTOK * C * C)
@@ -1201,7 +1214,8 @@ class _WindowAttentionFused(torch.autograd.Function):
         C = x.shape[1]
         datt, dwp, _ = linear_backward(att, wp, dy, w_proj, None, None, True)
         dqkv, _, _, dalpha, dbeta = attention_backward(qkv, None, None, lse, alpha_c, beta_c, dist, mask, datt, heads, scale, nb,
-                                                        None, ctx.needs_input_grad[4] or ctx.needs_input_grad[5], (alpha, beta))
+                                                        None, ctx.needs_input_grad[4] or ctx.needs_input_grad[5], (alpha, beta),
+                                                        packed=True)
         # the K third of d(qkv) sums to zero over every window (rows of dS sum to 0): its bias gradient is not summed
         dx, dwq, dbq = linear_backward(x, wq, dqkv, w_qkv, b_qkv, (C, 2 * C), ctx.needs_input_grad[0])
         return dx, dwq, dbq, dwp, dalpha, dbeta, None, None, None, None, None, None, None, None

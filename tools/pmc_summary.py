@@ -15,7 +15,7 @@ from collections import defaultdict
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
-KERNELS = {"win_fused_fwd_kernel": "pswin_win_attn_fused_fwd", "attn_fwd_kernel": "pswin_attn_fwd", "attn_bwd_kernel": "pswin_attn_bwd", "attn_bwd_pair_kernel": "pswin_attn_bwd", "ln_fwd_kernel": "pswin_ln_gather_fwd",
+KERNELS = {"win_fused_fwd_kernel": "pswin_win_attn_fused_fwd", "attn_fwd_kernel": "pswin_attn_fwd", "attn_bwd_kernel": "pswin_attn_bwd_ex", "attn_bwd_pair_kernel": "pswin_attn_bwd_ex", "ln_fwd_kernel": "pswin_ln_gather_fwd",
            "ln_bwd_kernel": "pswin_ln_gather_bwd", "window_gather_kernel": "pswin_window_gather",
            "window_scatter_add_kernel": "pswin_window_scatter_add"}
 
@@ -32,7 +32,7 @@ def collect(path, counter):
     return acc
 
 
-FETCH_FACTOR = {"pswin_attn_fwd": 1.0, "pswin_attn_bwd": 1.0, "pswin_win_attn_fused_fwd": 2.0}      # calibrated (see above); default 2.0 (wide row reads)
+FETCH_FACTOR = {"pswin_attn_fwd": 1.0, "pswin_attn_bwd_ex": 1.0, "pswin_win_attn_fused_fwd": 2.0}      # calibrated (see above); default 2.0 (wide row reads)
 fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
 out = {}
 for name in sorted(set(fetch) | set(write)):
