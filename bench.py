@@ -341,8 +341,9 @@ def main():
 
         # dominant hand-written kernel = the largest ms/step among the timed C-ABI entry points (computed, not assumed)
         own = [n for n in stats if n.startswith("pswin_")]
-        dom = max(own, key=lambda n: stats[n]["ms_per_step"])
-        roofline = roof(dom)
+        dom = max(own, key=lambda n: stats[n]["ms_per_step"]) if own else None
+        roofline = roof(dom) if dom else {"kernel": None, "bound": None, "achieved": None, "peak": None, "unit": None, "frac": None,
+                                          "note": "--kernel-steps 0: no per-kernel timing in this run"}
         # HBM bytes per launch from the PMC counters (FETCH_SIZE x correction + WRITE_SIZE, separate rocprofv3 --pmc passes,
         # tools/pmc_summary.py -> profiles/pmc_traffic.json); quoted only when collected on THIS build of the kernels
         traffic, tnote = None, "no PMC summary for this kernel"
@@ -351,7 +352,7 @@ def main():
                 pt = json.load(f)
             if pt.get("lib_digest") != digest:
                 tnote = f"profiles/pmc_traffic.json was collected on kernel sources {pt.get('lib_digest')}, this run is {digest}: not quoted"
-            elif dom in pt["kernels"]:
+            elif dom and dom in pt["kernels"]:
                 traffic, tnote = round(pt["kernels"][dom]["hbm_bytes_per_launch"]), "profiles/pmc_traffic.json"
         except (OSError, KeyError, ValueError):
             pass
