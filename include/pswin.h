@@ -318,6 +318,11 @@ int pswin_gemm_nt(const void* x, const void* w, const float* bias, void* y, long
  * with w_t = fc2.weight^T ([hidden N, K]), pre = the pre-activation fc1(x) without bias, bias = fc1.bias (f32 [N] or NULL).
  * dL/dh is never written.  partial: f32 [pswin_gemm_nt_partial_rows(M, tile_m), N]; its column sums are the fc1 bias
  * gradient (pswin_reduce_jobs).  tile_m: 64 or 128. */
+/* fc1 of the Mlp with its bias + nn.GELU in the GEMM epilogue (HOT:50-57):  pre = x . w^T (no bias; kept for the backward pass),
+ * h = gelu(pre + bias), both bf16 [M, N], bias f32 [N].  h is computed from the bf16-rounded pre: bit-identical to
+ * pswin_gemm_nt followed by pswin_bias_gelu_fwd, one pass over [M, N] less.  tile_m: 64 or 128. */
+int pswin_gemm_nt_gelu_fwd(const void* x, const void* w, const float* bias, void* pre, void* h, long long M, int K, int N, int tile_m,
+                           void* stream);
 int pswin_gemm_nt_partial_rows(long long M, int tile_m);
 int pswin_gemm_nt_gelu_bwd(const void* dy, const void* w_t, const void* pre, const float* bias, void* dpre, float* partial, long long M,
                            int K, int N, int tile_m, void* stream);

@@ -85,6 +85,9 @@ class Mlp(nn.Module):
             lp = self.fc1.__dict__.get("_lowp")                    # stage 0: fc1 + bias + GELU in one streaming kernel
             h = ops.fc1_gelu(x2, self.fc1.weight, self.fc1.bias, lp[0] if lp is not None else None)
             h = h.view(*x.shape[:-1], h.shape[-1])
+        elif self.fc1.bias is not None and ops.mlp_fused_supported(x2, self.fc1.weight.shape[0]):
+            # stages 1-3: fc1 (+ bias + GELU in its epilogue) and fc2 as one autograd node on the tiled HIP GEMM
+            return ops.mlp_fused(x2, self.fc1, self.fc2).view(*x.shape[:-1], self.fc2.weight.shape[0])
         else:
             y = _linear(x, self.fc1, cd, use_bias=False)
             if cd == torch.bfloat16 and ops.FUSED_GELU_BWD:

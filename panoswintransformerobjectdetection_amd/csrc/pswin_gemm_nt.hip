@@ -76,7 +76,9 @@ __device__ inline void glds16(const void* gsrc, char* lds_wave_base) {
 // EPI 0: y = acc (+ bias).  EPI 1 (the data gradient of fc2 fused with the backward of bias + GELU, HOT:50-58): acc = dL/dh of
 // the tile, aux = the Mlp's pre-activation [M, N], bias = fc1's bias; y = acc * gelu'(aux + bias) and the per-column sums of y
 // over the tile's rows (the fc1 bias gradient) go to partial[tile_m][N] -- dL/dh never exists in HBM and the separate
-// bias + GELU backward pass (two reads and a write of [M, 4C]) is gone.
+// bias + GELU backward pass (two reads and a write of [M, 4C]) is gone.  EPI 2 (fc1 + bias + nn.GELU forward): y = acc (the
+// pre-activation WITHOUT bias, kept for the backward pass) and, to the second output `aux`, h = gelu(bf16(acc) + bias) -- the
+// value the separate bias + GELU kernel computes from the stored pre-activation, bit for bit; the f32 bias comes in `partial`.
 template <int BM, int EPI>
 __global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_kernel(const unsigned short* __restrict__ X, const unsigned short* __restrict__ W,
                                                                  const float* __restrict__ bias, unsigned short* __restrict__ Y,
@@ -167,7 +169,8 @@ __global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_kernel(const unsigned s
     // acc[i][j][e] = Y[row m0 + wm * BM/2 + 16 i + c][column n0 + wn * 96 + 16 j + 4 g + e]
     const rsrc_t ys = __builtin_amdgcn_make_buffer_rsrc(Y, 0, (int)((size_t)M * N * 2), 0x00020000);
     const int d0 = 8 * (g >> 1) + 16 * (g & 1);
-    if constexpr (EPI == 0) {
+    if constexpr (EPI == 0 || EPI == 2) {
+        const rsrc_t hs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(aux), 0, EPI == 2 ? (int)((size_t)M * N * 2) : 0, 0x00020000);
 #pragma unroll
         for (int i = 0; i < RT; ++i) {
             const unsigned row = (unsigned)(m0 + wm * (BM / 2) + 16 * i + c);
@@ -180,7 +183,21 @@ __global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_kernel(const unsigned s
                     q1 += *reinterpret_cast<const f32x4*>(bias + n0 + wn * (BN / 2) + 32 * jp + 16 + 4 * g);
                 }
                 const unsigned off = base == 0xFFFFFF00u ? base : base + 64u * jp;
-                __builtin_amdgcn_raw_buffer_store_b128(pack_row8(q0, q1), ys, off, 0, 0);
+                const u32x4 yp = pack_row8(q0, q1);
+                __builtin_amdgcn_raw_buffer_store_b128(yp, ys, off, 0, 0);
+                if constexpr (EPI == 2) {
+                    // 8 consecutive columns n0 + wn * 96 + 32 jp + d0 .. of this lane's row: gelu(rounded pre-activation + fc1 bias)
+                    const float* bp = partial + n0 + wn * (BN / 2) + 32 * jp + d0;
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
+                    u32x4 hp;
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        const gelu_f32x2 hv = gelu_f2(gelu_f32x2{__builtin_bit_cast(float, yp[d] << 16) + (d < 2 ? b0[2 * d] : b1[2 * d - 4]),
+                                                                 __builtin_bit_cast(float, yp[d] & 0xffff0000u) + (d < 2 ? b0[2 * d + 1] : b1[2 * d - 3])});
+                        hp[d] = pk2(hv[0], hv[1]);
+                    }
+                    __builtin_amdgcn_raw_buffer_store_b128(hp, hs, off, 0, 0);
+                }
             }
         }
     } else {
@@ -272,6 +289,15 @@ int pswin_gemm_nt(const void* x, const void* w, const float* bias, void* y, long
 
 int pswin_gemm_nt_partial_rows(long long M, int tile_m) {
     return (M > 0 && (tile_m == 64 || tile_m == 128)) ? (int)((M + tile_m - 1) / tile_m) : PSWIN_ERR_ARG;
+}
+
+int pswin_gemm_nt_gelu_fwd(const void* x, const void* w, const float* bias, void* pre, void* h, long long M, int K, int N, int tile_m,
+                           void* stream) {
+    PSWIN_CHECK_ARG(x && w && bias && pre && h && pswin_gemm_nt_supported(M, K, N) && (tile_m == 64 || tile_m == 128));
+    PSWIN_CHECK_ARG(aligned16(x) && aligned16(w) && aligned16(pre) && aligned16(h) && aligned16(bias));
+    float* b = const_cast<float*>(bias);
+    if (tile_m == 128) return launch_nt<128, 2>(x, w, nullptr, pre, (int)M, N, K, (hipStream_t)stream, h, b);
+    return launch_nt<64, 2>(x, w, nullptr, pre, (int)M, N, K, (hipStream_t)stream, h, b);
 }
 
 int pswin_gemm_nt_gelu_bwd(const void* dy, const void* w_t, const void* pre, const float* bias, void* dpre, float* partial, long long M,

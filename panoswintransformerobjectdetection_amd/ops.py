@@ -25,6 +25,9 @@ GEMM_NT = os.environ.get("PSWIN_GEMM_NT", "1") != "0"
 GEMM_TN = os.environ.get("PSWIN_GEMM_TN", "0") != "0"
 # fc2's data gradient + the backward of fc1's bias + GELU in one kernel (pswin_gemm_nt_gelu_bwd); PSWIN_FUSED_GELU_BWD=0: two kernels
 FUSED_GELU_BWD = os.environ.get("PSWIN_FUSED_GELU_BWD", "1") != "0"
+# fc1 with the bias + GELU in its epilogue (pswin_gemm_nt_gelu_fwd) and fc2 as one autograd node; PSWIN_FUSED_MLP=0: GEMM, then a
+# streaming bias + GELU pass
+FUSED_MLP = os.environ.get("PSWIN_FUSED_MLP", "1") != "0"
 
 
 def _dev_key(device):
@@ -955,6 +958,75 @@ class _BiasGeluLinear(torch.autograd.Function):
             db = sum_rows(ws, lib.pswin_bias_gelu_partial_rows(M, N, dtype_code(y2)), N, owners=(b1,)) if b is not None else None
         _, dw, _ = linear_backward(h, wb, dout, w2, None, None, False)
         return dpre.view_as(y2), db, dw, None, None
+
+
+class _MlpFused(torch.autograd.Function):
+    """fc2(gelu(fc1(x) + b1)) WITHOUT fc2's bias for bf16 rows on the tiled GEMM (stages 1-3; HOT:44-61): fc1 with the bias + GELU
+    in its epilogue (pswin_gemm_nt_gelu_fwd: the pre-activation is written once and never re-read in the forward pass), fc2;
+    backward: fc2's data gradient with the GELU backward and the fc1 bias gradient in its epilogue (pswin_gemm_nt_gelu_bwd),
+    fc1's data gradient on the transposed weight copy, the two weight gradients as everywhere."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, w1_lp, w1_lp_t, w2_lp, w2_lp_t):
+        x = x.contiguous()
+        M, K = x.shape
+        w1b = w1_lp if w1_lp is not None else w1.to(x.dtype)
+        w2b = w2_lp if w2_lp is not None else w2.to(x.dtype)
+        N, C = w1b.shape[0], w2b.shape[0]
+        b = b1.detach().float().contiguous()
+        pre = torch.empty(M, N, dtype=x.dtype, device=x.device)
+        h = torch.empty_like(pre)
+        call("pswin_gemm_nt_gelu_fwd", x, ptr(x), ptr(w1b), ptr(b), ptr(pre), ptr(h), M, K, N, gemm_nt_tile(M, K, N) or 64,
+             algo_bytes=2 * (M * K + 2 * M * N + N * K), algo_flops=2 * M * K * N)
+        tile = gemm_nt_tile(M, N, C)
+        if tile:
+            out = gemm_nt(h, w2b, None, tile)
+        else:
+            with _lib.timed("lib_gemm_fwd", 2 * (M * N + M * C + N * C), 2 * M * N * C):
+                out = F.linear(h, w2b)
+        ctx.save_for_backward(x, pre, h, b, w1b, w1_lp_t, w2b, w2_lp_t)
+        ctx.params = (w1, b1, w2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, pre, h, b, w1b, w1bt, w2b, w2bt = ctx.saved_tensors
+        w1, b1, w2 = ctx.params
+        M, N = pre.shape
+        C = w2b.shape[0]
+        dout = dout.contiguous()
+        lib = _lib.load()
+        if w2bt is not None:
+            tile = gemm_nt_tile(M, C, N) or 64
+            dpre = torch.empty_like(pre)
+            rows = lib.pswin_gemm_nt_partial_rows(M, tile)
+            ws = torch.empty(rows, N, dtype=torch.float32, device=pre.device)
+            call("pswin_gemm_nt_gelu_bwd", pre, ptr(dout), ptr(w2bt), ptr(pre), ptr(b), ptr(dpre), ptr(ws), M, C, N, tile,
+                 algo_bytes=2 * (M * C + 2 * M * N + N * C), algo_flops=2 * M * N * C)
+            db = sum_rows(ws, rows, N, owners=(b1,))
+        else:
+            with _lib.timed("lib_gemm_dgrad", 2 * (M * N + M * C + N * C), 2 * M * N * C):
+                dh = dout @ w2b
+            dpre = torch.empty_like(pre)
+            ws = torch.empty(lib.pswin_bias_gelu_workspace(M, N), dtype=torch.float32, device=pre.device)
+            call("pswin_bias_gelu_bwd", pre, ptr(dh), ptr(pre), dtype_code(pre), ptr(b), ptr(dpre), None, ptr(ws), M, N,
+                 algo_bytes=3 * pre.numel() * pre.element_size())
+            db = sum_rows(ws, lib.pswin_bias_gelu_partial_rows(M, N, dtype_code(pre)), N, owners=(b1,))
+        _, dw2, _ = linear_backward(h, w2b, dout, w2, None, None, False)
+        dx, dw1, _ = linear_backward(x, w1b, dpre, w1, None, None, ctx.needs_input_grad[0], w1bt)
+        return dx, dw1, db, dw2, None, None, None, None
+
+
+def mlp_fused_supported(x2d, hidden):
+    return (GEMM_NT and FUSED_GELU_BWD and FUSED_MLP and x2d.dtype == torch.bfloat16 and x2d.is_cuda and x2d.dim() == 2 and x2d.shape[0] >= 64
+            and bool(_lib.load().pswin_gemm_nt_supported(x2d.shape[0], x2d.shape[1], hidden)))
+
+
+def mlp_fused(x2d, fc1, fc2):
+    """fc2_nobias(gelu(fc1(x2d))) as one autograd node on the tiled GEMM kernels: see _MlpFused."""
+    l1, l2 = fc1.__dict__.get("_lowp"), fc2.__dict__.get("_lowp")
+    return _MlpFused.apply(x2d, fc1.weight, fc1.bias, fc2.weight, l1[0] if l1 is not None else None, fc1.__dict__.get("_lowp_t"),
+                           l2[0] if l2 is not None else None, fc2.__dict__.get("_lowp_t"))
 
 
 def bias_gelu_linear(y, bias1, lin2):

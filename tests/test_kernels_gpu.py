@@ -835,3 +835,55 @@ def test_gelu_backward_fused_into_the_fc2_data_gradient(ops, M, C, tile):
     a, b = run(True), run(False)
     for u, v in zip(a, b):
         assert torch.allclose(u, v, rtol=2e-2, atol=2e-2 * float(v.abs().max())), (u - v).abs().max()
+
+
+@pytest.mark.parametrize("M,C,tile", [(16384, 192, 128), (4096, 384, 64), (333, 192, 64), (1024, 768, 64)])
+def test_fc1_with_the_gelu_in_its_epilogue(ops, M, C, tile):
+    """pswin_gemm_nt_gelu_fwd writes the pre-activation (bit-identical to the tiled GEMM) and gelu(pre + b1) (the streaming bias +
+    GELU kernel's value from the same rounded pre-activation, within one bf16 ulp); then the single-node MLP ops.mlp_fused against
+    the chain linear -> bias_gelu_linear (output and every gradient)."""
+    import torch.nn as nn
+    torch.manual_seed(M + C)
+    N = 4 * C
+    x = torch.randn(M, C, device=DEV).to(torch.bfloat16)
+    w1 = (torch.randn(N, C, device=DEV) / math.sqrt(C)).to(torch.bfloat16)
+    b1 = torch.randn(N, device=DEV) * 0.1
+    pre = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    h = torch.empty_like(pre)
+    ops.call("pswin_gemm_nt_gelu_fwd", x, ops.ptr(x), ops.ptr(w1), ops.ptr(b1), ops.ptr(pre), ops.ptr(h), M, C, N, tile)
+    pre_ref = ops.gemm_nt(x, w1, None, tile)
+    h_ref = ops.bias_gelu(pre_ref, b1)
+    assert torch.equal(pre, pre_ref)
+    # the epilogue evaluates the GELU two elements at a time on packed-f32 instructions (folded constants, another product
+    # order): the same value to f32 rounding, so at most one bf16 ulp apart from the streaming kernel, and that rarely
+    d = (h.float() - h_ref.float()).abs()
+    assert bool((d <= h_ref.float().abs() * 2.0 ** -7 + 1e-30).all()), d.max()
+    assert float((d > 0).float().mean()) < 1e-3
+    fp = F.gelu(x.float() @ w1.float().t() + b1)
+    assert torch.allclose(h.float(), fp, rtol=2e-2, atol=2e-2)
+
+    fc1, fc2 = nn.Linear(C, N).to(DEV), nn.Linear(N, C).to(DEV)
+    with torch.no_grad():
+        fc1.weight.copy_(w1.float()); fc1.bias.copy_(b1)
+    for lin in (fc1, fc2):
+        wb = lin.weight.detach().to(torch.bfloat16)
+        lin.__dict__["_lowp"] = (wb, None)
+        lin.__dict__["_lowp_t"] = wb.t().contiguous()
+    g = torch.randn(M, C, device=DEV).to(torch.bfloat16)
+    assert ops.mlp_fused_supported(x, N)
+
+    def run(fused):
+        xx = x.clone().requires_grad_(True)
+        for p in (*fc1.parameters(), *fc2.parameters()):
+            p.grad = None
+        if fused:
+            out = ops.mlp_fused(xx, fc1, fc2)
+        else:
+            out = ops.bias_gelu_linear(ops.linear(xx, fc1, torch.bfloat16, use_bias=False), fc1.bias, fc2)
+        out.backward(g)
+        return out.detach().float(), xx.grad.float(), fc1.weight.grad.clone(), fc1.bias.grad.clone(), fc2.weight.grad.clone()
+    a, b = run(True), run(False)
+    for u, v in zip(a, b):
+        assert torch.allclose(u, v, rtol=2e-2, atol=2e-2 * float(v.abs().max())), (u - v).abs().max()
+    with torch.no_grad():
+        assert torch.equal(ops.mlp_fused(x, fc1, fc2), a[0].to(torch.bfloat16))
