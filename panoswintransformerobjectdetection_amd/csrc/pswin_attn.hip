@@ -60,11 +60,31 @@ struct AttnArgs {
 };
 
 
-// stage column h of the [169][heads] tables into this wave's LDS
-__device__ inline void load_tables(const AttnArgs& a, int h, int lane, float* tab_a, float* tab_b) {
-    for (int t = lane; t < NBINS; t += 64) {
-        tab_b[t] = a.beta[t * a.heads + h];
-        tab_a[t] = a.dist ? a.alpha[t * a.heads + h] : 0.f;
+// stage column h of the [169][heads] tables into this wave's LDS: all loads first (tables_fetch), the LDS writes later
+// (tables_store), so that they share one memory round trip with the other loads of a kernel's preamble
+struct TabRaw {
+    float b[3], a[3];
+};
+static_assert(NBINS <= 3 * 64, "three table entries per lane");
+__device__ inline TabRaw tables_fetch(const AttnArgs& a, int h, int lane) {
+    TabRaw r;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int t = lane + 64 * k;
+        const bool ok = t < NBINS;
+        r.b[k] = ok ? a.beta[t * a.heads + h] : 0.f;
+        r.a[k] = (ok && a.dist) ? a.alpha[t * a.heads + h] : 0.f;
+    }
+    return r;
+}
+__device__ inline void tables_store(const TabRaw& r, int lane, float* tab_a, float* tab_b) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int t = lane + 64 * k;
+        if (t < NBINS) {
+            tab_b[t] = r.b[k];
+            tab_a[t] = r.a[k];
+        }
     }
 }
 
@@ -134,21 +154,28 @@ __global__ __launch_bounds__(64 * WAVES, (DT == PSWIN_BF16 ? (NQ == 2 ? 3 : 2) :
     FwdTiles<DT, NQ> cur;
     load_tiles(0, cur);              // in flight while the bias is being built
 
-    load_tables(a, h, lane, tab_a, tab_b);
-    __builtin_amdgcn_wave_barrier();
     const float inv_scale = 1.0f / a.scale;
     const float sl2e = a.scale * LOG2E;          // scores are kept unscaled: p = exp2((s' - m') * scale * log2 e)
     // bias of (wb, h) / scale for this item's queries: query on the lane, 4 consecutive keys per quad; in VGPRs for
-    // the whole batch loop
+    // the whole batch loop.  Its table columns and distance / mask quads are all requested before the first is used.
     f32x4 bias[NQ][4];
     {
         const float* dtile = a.dist ? a.dist + (size_t)(wb % a.n_dist) * (PADT * PADT) : nullptr;
         const float* mtile = a.mask ? a.mask + (size_t)(wb % a.n_mask) * (PADT * PADT) : nullptr;
+        const TabRaw tabs = tables_fetch(a, h, lane);
+        BiasRaw raw[NQ][4];
+#pragma unroll
+        for (int tq = 0; tq < NQ; ++tq)
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj) raw[tq][tj] = bias_fetch<false>(dtile, mtile, 16 * (ti0 + tq) + c, 16 * tj + 4 * g);
+        __builtin_amdgcn_sched_barrier(0);
+        tables_store(tabs, lane, tab_a, tab_b);
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int tq = 0; tq < NQ; ++tq)
 #pragma unroll
             for (int tj = 0; tj < 4; ++tj)
-                bias[tq][tj] = bias_quad<false>(dtile, mtile, tab_a, tab_b, 16 * (ti0 + tq) + c, 16 * tj + 4 * g, inv_scale);
+                bias[tq][tj] = bias_from<false>(raw[tq][tj], dtile, mtile, tab_a, tab_b, 16 * (ti0 + tq) + c, 16 * tj + 4 * g, inv_scale);
     }
 
     for (int r = 0; r < a.reps_per_chunk; ++r) {
@@ -287,17 +314,26 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_kernel(AttnArgs a) {
     Tiles4<DT> cur, nxt;
     load_tiles(0, cur);              // in flight while the bias is being built
 
-    load_tables(a, h, lane, tab_a, tab_b);
-    __builtin_amdgcn_wave_barrier();
     const float inv_scale = 1.0f / a.scale;
     const float sl2e = a.scale * LOG2E;
     // bias / scale in the backward layout: rows i = 16 ti + 4 g + e on the registers, key j = 16 tj + c on the lane
     f32x4 bias[4][4];
+    {
+        const TabRaw tabs = tables_fetch(a, h, lane);
+        BiasRaw raw[4][4];
 #pragma unroll
-    for (int ti = 0; ti < 4; ++ti)
+        for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
-        for (int tj = 0; tj < 4; ++tj)
-            bias[ti][tj] = bias_quad<true>(dtile, mtile, tab_a, tab_b, 16 * ti + 4 * g, 16 * tj + c, inv_scale);
+            for (int tj = 0; tj < 4; ++tj) raw[ti][tj] = bias_fetch<true>(dtile, mtile, 16 * ti + 4 * g, 16 * tj + c);
+        __builtin_amdgcn_sched_barrier(0);
+        tables_store(tabs, lane, tab_a, tab_b);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ti = 0; ti < 4; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj)
+                bias[ti][tj] = bias_from<true>(raw[ti][tj], dtile, mtile, tab_a, tab_b, 16 * ti + 4 * g, 16 * tj + c, inv_scale);
+    }
 
     f32x4 gsum[4][4];   // sum over the batch loop of dS
 #pragma unroll
@@ -494,6 +530,7 @@ __global__ __launch_bounds__(128, 2) void attn_bwd_pair_kernel(AttnArgs a) {
 
     struct Ops {
         Frag<DT> q[2], d[2], k[4], v[4];
+        float lse;                    // log-sum-exp of query 32 w + (lane & 31)
     };
     unsigned kv_off[4], q_off[2], do_off[2], dkv_off[4], dq_off[2];   // per-lane byte offsets within a window
 #pragma unroll
@@ -514,6 +551,11 @@ __global__ __launch_bounds__(128, 2) void attn_bwd_pair_kernel(AttnArgs a) {
         const rsrc_t kb = window_rsrc<DT>(a.k, head0, a.ld_qkv);
         const rsrc_t vb = window_rsrc<DT>(a.v, head0, a.ld_qkv);
         const rsrc_t db = window_rsrc<DT>(a.dout, (row0 * (size_t)a.ld_out + h * HD) * 2, a.ld_out);
+        // The log-sum-exp values of this wave's 32 queries travel with the operands, one per lane, requested FIRST (loads return
+        // in order: they are there whenever an operand fragment is) and are handed to the lanes that need them by ds_bpermute.
+        // Loaded where they are used, at the top of the next iteration, they were a memory round trip per image that nothing
+        // covered: that load sits behind the previous image's stores in the one in-order counter.
+        t.lse = a.lse[(win_ * a.heads + h) * PADT + 32 * w + (lane & 31)];
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
             t.k[tt] = load_frag_at<DT>(kb, kv_off[tt]);
@@ -528,19 +570,30 @@ __global__ __launch_bounds__(128, 2) void attn_bwd_pair_kernel(AttnArgs a) {
     Ops cur;
     load_ops(0, cur);                 // in flight while the bias is being built
 
-    if (w == 0) load_tables(a, h, lane, tab_a, tab_b);
-    __syncthreads();
     const float inv_scale = 1.0f / a.scale;
     const float sl2e = a.scale * LOG2E;
-    // bias / scale for this wave's query tiles: rows i = 16 (2w + tt) + 4 g + e on the registers, key j = 16 tj + c
+    // bias / scale for this wave's query tiles: rows i = 16 (2w + tt) + 4 g + e on the registers, key j = 16 tj + c.  The table
+    // columns and the distance / mask quads are all requested before the first is used (one round trip, not nine).
     f32x4 bias[2][4], gsum[2][4];
+    {
+        TabRaw tabs;
+        if (w == 0) tabs = tables_fetch(a, h, lane);
+        BiasRaw raw[2][4];
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt)
+        for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
-        for (int tj = 0; tj < 4; ++tj) {
-            bias[tt][tj] = bias_quad<true>(dtile, mtile, tab_a, tab_b, 16 * (2 * w + tt) + 4 * g, 16 * tj + c, inv_scale);
-            gsum[tt][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+            for (int tj = 0; tj < 4; ++tj) raw[tt][tj] = bias_fetch<true>(dtile, mtile, 16 * (2 * w + tt) + 4 * g, 16 * tj + c);
+        __builtin_amdgcn_sched_barrier(0);
+        if (w == 0) tables_store(tabs, lane, tab_a, tab_b);
+        __syncthreads();
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj) {
+                bias[tt][tj] = bias_from<true>(raw[tt][tj], dtile, mtile, tab_a, tab_b, 16 * (2 * w + tt) + 4 * g, 16 * tj + c, inv_scale);
+                gsum[tt][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+    }
 
     for (int r = 0; r < a.reps_per_chunk; ++r) {
         const size_t win = (size_t)(chunk * a.reps_per_chunk + r) * a.nb + wb;
@@ -556,16 +609,15 @@ __global__ __launch_bounds__(128, 2) void attn_bwd_pair_kernel(AttnArgs a) {
             *reinterpret_cast<bf16x8*>(qimg + img32_off(16 * tt + c, g)) = cur.q[tt].v;
             *reinterpret_cast<bf16x8*>(doimg + img32_off(16 * tt + c, g)) = cur.d[tt].v;
         }
-        const float* lse_row = a.lse + (win * a.heads + h) * PADT;
         Frag<DT> pf[4], dsf[4];
         {
             f32x4 p4[2][4], ds4[2][4];
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
-                const int ti = 2 * w + tt;
-                f32x4 lse4 = *reinterpret_cast<const f32x4*>(lse_row + 16 * ti + 4 * g);
+                f32x4 lse4;               // rows 16 tt + 4 g + e of this wave's half
 #pragma unroll
-                for (int e = 0; e < 4; ++e) lse4[e] = -lse4[e] * LOG2E;
+                for (int e = 0; e < 4; ++e)
+                    lse4[e] = -LOG2E * __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(4 * (16 * tt + 4 * g + e), __builtin_bit_cast(int, cur.lse)));
                 f32x4 delta = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int tj = 0; tj < 4; ++tj) {

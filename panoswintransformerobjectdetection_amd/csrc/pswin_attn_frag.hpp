@@ -293,13 +293,26 @@ __device__ inline int rel_b(int j) { return 13 * (j / PSWIN_WS) + j % PSWIN_WS; 
 // QUERY_ON_REGS = true  (backward): i = qi + e,   j = kj fixed        tile row = j (transposed tiles), quad along i
 // The result is bias / scale: the kernels run the MFMAs on the UNSCALED q (score' = q.k + bias/scale) and fold the
 // scale into the exp2 argument, which removes the per-image q*scale pass.  Branch-free (selects only).
+// In two halves, so that a kernel can request the distance / mask quads of ALL its tiles (and its table columns) before it
+// waits for the first: built one quad at a time, each quad's loads were a memory round trip of their own in front of the
+// batch loop (8-16 of them per work item, as long as the loop itself at 4-8 images per item).
+struct BiasRaw {
+    f32x4 d, m;
+};
 template <bool QUERY_ON_REGS>
-__device__ inline f32x4 bias_quad(const float* dtile, const float* mtile, const float* tab_a, const float* tab_b,
-                                  int qi, int kj, float inv_scale) {
+__device__ inline BiasRaw bias_fetch(const float* dtile, const float* mtile, int qi, int kj) {
     const int row = QUERY_ON_REGS ? kj : qi, col = QUERY_ON_REGS ? qi : kj;
-    f32x4 d4 = {0.f, 0.f, 0.f, 0.f}, m4 = {0.f, 0.f, 0.f, 0.f};
-    if (dtile) d4 = *reinterpret_cast<const f32x4*>(dtile + row * PADT + col);
-    if (mtile) m4 = *reinterpret_cast<const f32x4*>(mtile + row * PADT + col);
+    BiasRaw r;
+    r.d = f32x4{0.f, 0.f, 0.f, 0.f};
+    r.m = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (dtile) r.d = *reinterpret_cast<const f32x4*>(dtile + row * PADT + col);
+    if (mtile) r.m = *reinterpret_cast<const f32x4*>(mtile + row * PADT + col);
+    return r;
+}
+template <bool QUERY_ON_REGS>
+__device__ inline f32x4 bias_from(const BiasRaw& raw, const float* dtile, const float* mtile, const float* tab_a, const float* tab_b,
+                                  int qi, int kj, float inv_scale) {
+    const f32x4 d4 = raw.d, m4 = raw.m;
     f32x4 r;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -316,5 +329,10 @@ __device__ inline f32x4 bias_quad(const float* dtile, const float* mtile, const 
         r[e] = (j < TOK) ? val : -INFINITY;          // padded key: never receives weight
     }
     return r;
+}
+template <bool QUERY_ON_REGS>
+__device__ inline f32x4 bias_quad(const float* dtile, const float* mtile, const float* tab_a, const float* tab_b,
+                                  int qi, int kj, float inv_scale) {
+    return bias_from<QUERY_ON_REGS>(bias_fetch<QUERY_ON_REGS>(dtile, mtile, qi, kj), dtile, mtile, tab_a, tab_b, qi, kj, inv_scale);
 }
 }  // namespace

@@ -126,9 +126,12 @@ __global__ __launch_bounds__(THREADS, 2) void skinny_gemm_kernel(const void* __r
             }
         }
     };
-    for (int tile = blockIdx.x * (THREADS / 64) + wave; tile < ntiles; tile += gridDim.x * (THREADS / 64)) {
-        bf16x8 b[RT][KS];
-        load_b(tile, b);
+    // The activation rows of a wave's NEXT tile are requested as soon as the MFMAs of the current one have consumed the
+    // registers, i.e. before the epilogue's stores: loads issued behind stores wait for them (one in-order counter), which
+    // left each wave with nothing in flight between its last store and the arrival of its next rows.
+    const int tile0 = blockIdx.x * (THREADS / 64) + wave, tstep = gridDim.x * (THREADS / 64);
+    bf16x8 b[RT][KS];
+    auto row_tile = [&](int tile) {
         f32x4 acc[RT][NT];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt)
@@ -157,6 +160,20 @@ __global__ __launch_bounds__(THREADS, 2) void skinny_gemm_kernel(const void* __r
                 for (int rt = 0; rt < RT; ++rt) acc[rt][nt0 + j] = mfma32(a[bi & 1][j], b[rt][s_], acc[rt][nt0 + j]);
             __builtin_amdgcn_sched_barrier(0);
         }
+        // EPI 2: every dL/dh load of the tile before its first store, for the same reason
+        [[maybe_unused]] u32x4 dhv[RT][NT / 2];
+        if constexpr (EPI == 2) {
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
+                const unsigned row = (unsigned)tile * ROWS + 16 * rt + c;
+                const unsigned base = row < (unsigned)M ? row * (unsigned)(N * 2) + 2u * d0 : 0xFFFFFF00u;
+#pragma unroll
+                for (int np = 0; np < NT / 2; ++np)
+                    dhv[rt][np] = __builtin_amdgcn_raw_buffer_load_b128(as, base == 0xFFFFFF00u ? base : base + 64u * np, 0, 0);   // rows >= M: zeros
+            }
+        }
+        if (tile + tstep < ntiles) load_b(tile + tstep, b);
+        __builtin_amdgcn_sched_barrier(0);
         // acc[rt][nt][e] = Y[row 16 rt + c][column 16 nt + 4 g + e]
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
@@ -179,7 +196,7 @@ __global__ __launch_bounds__(THREADS, 2) void skinny_gemm_kernel(const void* __r
                 if constexpr (EPI == 2) {
                     // 8 consecutive columns 32 np + d0 .. of this lane's row, the layout of the 16-byte aux load
                     exchange_row8(q0, q1);
-                    const u32x4 dh = __builtin_amdgcn_raw_buffer_load_b128(as, off, 0, 0);     // rows >= M: zeros
+                    const u32x4 dh = dhv[rt][np];
                     float v[8];
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {
@@ -202,6 +219,14 @@ __global__ __launch_bounds__(THREADS, 2) void skinny_gemm_kernel(const void* __r
                 }
             }
         }
+    };
+    // The first tile is peeled off the loop: the loop header is then reached only with "next rows requested, then this tile's
+    // stores" outstanding on both edges, and the wait in front of the first MFMA counts past the stores (with the first load
+    // in the preheader the merged state made it wait for every store).
+    if (tile0 < ntiles) {
+        load_b(tile0, b);
+        row_tile(tile0);
+        for (int tile = tile0 + tstep; tile < ntiles; tile += tstep) row_tile(tile);
     }
     if constexpr (EPI == 2) {
         __syncthreads();

@@ -30,6 +30,9 @@ using namespace pswin;
 namespace {
 
 constexpr int BN = 192, BK = 64, NT_THREADS = 256;
+#ifndef PSWIN_NT_PROBE
+#define PSWIN_NT_PROBE 0      // tools/probe/nt_probe.hip builds ablated loops (1: no loads inside the k loop, 2: loads and barriers only)
+#endif
 using rsrc_t = __amdgpu_buffer_rsrc_t;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 
@@ -85,6 +88,8 @@ __global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_kernel(const unsigned s
                                                                  int M, int N, int K, int tiles_m, int tiles_n,
                                                                  const unsigned short* __restrict__ aux, float* __restrict__ partial) {
     constexpr int RT = BM / 32;                       // 16-row tiles per wave (waves: 2 along M x 2 along N)
+    constexpr int WROWS = BM / 2;                     // rows per wave
+    constexpr int AJ = BM / 32, BJ = BN / 32;         // 8-row LDS-DMA blocks per wave and k-step (4 waves)
     constexpr int CT = BN / 32;                       // 16-column tiles per wave: 6
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
     extern __shared__ __attribute__((aligned(1024))) char smem[];       // 2 stages: [A tile | B tile]
@@ -106,23 +111,23 @@ __global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_kernel(const unsigned s
     // LDS-DMA source addressing: a wave instruction moves 8 rows x 128 B; lane i -> row i / 8, physical chunk i & 7, which
     // holds the row's logical chunk (i & 7) ^ (row & 7)
     const int lrow = lane >> 3, lch = (lane & 7) ^ (lrow & 7);                    // (row & 7) == lrow: row blocks start at multiples of 8
-    const unsigned short* a_src[BM / 32];                                         // A: BM / 8 row blocks over 4 waves
-    const unsigned short* b_src[BN / 32];                                         // B: 24 row blocks over 4 waves
+    const unsigned short* a_src[AJ];                                              // A: BM / 8 row blocks over the waves
+    const unsigned short* b_src[BJ];                                              // B: 24 row blocks over the waves
 #pragma unroll
-    for (int j = 0; j < BM / 32; ++j) {
-        int row = m0 + (wave * (BM / 32) + j) * 8 + lrow;
+    for (int j = 0; j < AJ; ++j) {
+        int row = m0 + (wave * AJ + j) * 8 + lrow;
         row = row < M ? row : M - 1;                                              // rows past M: valid memory, results never stored
         a_src[j] = X + (size_t)row * K + 8 * lch;
     }
 #pragma unroll
-    for (int j = 0; j < BN / 32; ++j) b_src[j] = W + (size_t)(n0 + (wave * (BN / 32) + j) * 8 + lrow) * K + 8 * lch;
+    for (int j = 0; j < BJ; ++j) b_src[j] = W + (size_t)(n0 + (wave * BJ + j) * 8 + lrow) * K + 8 * lch;
     auto issue = [&](int kt, int stage) {
         char* sa = smem + stage * STAGE;
         char* sb = sa + A_BYTES;
 #pragma unroll
-        for (int j = 0; j < BM / 32; ++j) glds16(a_src[j] + kt * BK, sa + (wave * (BM / 32) + j) * 1024);
+        for (int j = 0; j < AJ; ++j) glds16(a_src[j] + kt * BK, sa + (wave * AJ + j) * 1024);
 #pragma unroll
-        for (int j = 0; j < BN / 32; ++j) glds16(b_src[j] + kt * BK, sb + (wave * (BN / 32) + j) * 1024);
+        for (int j = 0; j < BJ; ++j) glds16(b_src[j] + kt * BK, sb + (wave * BJ + j) * 1024);
     };
 
     f32x4 acc[RT][CT];
@@ -133,62 +138,98 @@ __global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_kernel(const unsigned s
 
     // fragment read offsets: row (16 i + c) of the wave's block, logical chunk 4 ks + g -> physical chunk ^ (row & 7); the wave's
     // row blocks start at multiples of 16, so (row & 7) = c & 7
-    const int a_lane = (wm * (BM / 2) + c) * 128, b_lane = (wn * (BN / 2) + c) * 128;
+    const int a_lane = (wm * WROWS + c) * 128, b_lane = (wn * (BN / 2) + c) * 128;
     int choff[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) choff[ks] = ((4 * ks + g) ^ (c & 7)) << 4;
+
+    // EPI 1: the tile of pre-activations the epilogue needs (12 x 16 B per lane at BM = 128) is requested during the last k-step,
+    // so that it arrives under that step's MFMAs instead of in front of an idle epilogue
+    const int d0 = 8 * (g >> 1) + 16 * (g & 1);
+    [[maybe_unused]] u32x4 yv[CT / 2][RT];
+    [[maybe_unused]] const rsrc_t as = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(aux), 0, EPI == 1 ? (int)((size_t)M * N * 2) : 0, 0x00020000);
+    auto aux_off = [&](int jp, int i) {
+        const unsigned row = (unsigned)(m0 + wm * WROWS + 16 * i + c);
+        return row < (unsigned)M ? row * (unsigned)(N * 2) + (unsigned)((n0 + wn * (BN / 2) + 32 * jp + d0) * 2) : 0xFFFFFF00u;
+    };
 
     const int KT = K / BK;
     issue(0, 0);
     for (int kt = 0; kt < KT; ++kt) {
         __syncthreads();                              // (vmcnt(0) + barrier) stage kt landed for every wave; stage kt-1 fully consumed
-        if (kt + 1 < KT) issue(kt + 1, (kt + 1) & 1);
+        if (kt + 1 < KT && PSWIN_NT_PROBE != 1) issue(kt + 1, (kt + 1) & 1);
+        if (PSWIN_NT_PROBE == 2) continue;
         const char* sa = smem + (kt & 1) * STAGE + a_lane;
         const char* sb = smem + (kt & 1) * STAGE + A_BYTES + b_lane;
-        // fragments of the second 32-deep half are read under the MFMAs of the first (two register sets)
+        // the fragments of the second 32-deep half are requested after the first four MFMAs of the first half and arrive under its
+        // other twenty (two register sets): the wait in front of the first MFMA then covers the first set only
         u32x4 af[2][RT], bf[2][CT];
 #pragma unroll
         for (int i = 0; i < RT; ++i) af[0][i] = *reinterpret_cast<const u32x4*>(sa + i * 2048 + choff[0]);
 #pragma unroll
         for (int j = 0; j < CT; ++j) bf[0][j] = *reinterpret_cast<const u32x4*>(sb + j * 2048 + choff[0]);
-#pragma unroll
-        for (int i = 0; i < RT; ++i) af[1][i] = *reinterpret_cast<const u32x4*>(sa + i * 2048 + choff[1]);
-#pragma unroll
-        for (int j = 0; j < CT; ++j) bf[1][j] = *reinterpret_cast<const u32x4*>(sb + j * 2048 + choff[1]);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int j = 0; j < CT; ++j)
+            for (int j = 0; j < CT; ++j) {
 #pragma unroll
                 for (int i = 0; i < RT; ++i) acc[i][j] = mfma32(bf[ks][j], af[ks][i], acc[i][j]);      // transposed product: rows = output columns
+                if (ks == 0 && j == 0) {
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < RT; ++i) af[1][i] = *reinterpret_cast<const u32x4*>(sa + i * 2048 + choff[1]);
+#pragma unroll
+                    for (int jj = 0; jj < CT; ++jj) bf[1][jj] = *reinterpret_cast<const u32x4*>(sb + jj * 2048 + choff[1]);
+                    if constexpr (EPI == 1) {
+                        if (kt == KT - 1) {
+#pragma unroll
+                            for (int jp = 0; jp < CT / 2; ++jp)
+#pragma unroll
+                                for (int i2 = 0; i2 < RT; ++i2) yv[jp][i2] = __builtin_amdgcn_raw_buffer_load_b128(as, aux_off(jp, i2), 0, 0);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
             __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 
     // acc[i][j][e] = Y[row m0 + wm * BM/2 + 16 i + c][column n0 + wn * 96 + 16 j + 4 g + e]
     const rsrc_t ys = __builtin_amdgcn_make_buffer_rsrc(Y, 0, (int)((size_t)M * N * 2), 0x00020000);
-    const int d0 = 8 * (g >> 1) + 16 * (g & 1);
     if constexpr (EPI == 0 || EPI == 2) {
         const rsrc_t hs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(aux), 0, EPI == 2 ? (int)((size_t)M * N * 2) : 0, 0x00020000);
+        // the bias values of this lane's columns are loaded before the first store: a load issued behind stores waits for them
+        // (one in-order counter), which made every row tile of the epilogue a memory round trip
+        f32x4 bq[CT / 2][2];
+#pragma unroll
+        for (int jp = 0; jp < CT / 2; ++jp) {
+            const float* bp = EPI == 2 ? partial + n0 + wn * (BN / 2) + 32 * jp + d0 : bias + n0 + wn * (BN / 2) + 32 * jp + 4 * g;
+            const bool have = EPI == 2 || bias != nullptr;
+            bq[jp][0] = have ? *reinterpret_cast<const f32x4*>(bp) : f32x4{0.f, 0.f, 0.f, 0.f};
+            bq[jp][1] = have ? *reinterpret_cast<const f32x4*>(bp + (EPI == 2 ? 4 : 16)) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < RT; ++i) {
-            const unsigned row = (unsigned)(m0 + wm * (BM / 2) + 16 * i + c);
+            const unsigned row = (unsigned)(m0 + wm * WROWS + 16 * i + c);
             const unsigned base = row < (unsigned)M ? row * (unsigned)(N * 2) + (unsigned)((n0 + wn * (BN / 2) + d0) * 2) : 0xFFFFFF00u;
 #pragma unroll
             for (int jp = 0; jp < CT / 2; ++jp) {
                 f32x4 q0 = acc[i][2 * jp], q1 = acc[i][2 * jp + 1];
-                if (bias) {
-                    q0 += *reinterpret_cast<const f32x4*>(bias + n0 + wn * (BN / 2) + 32 * jp + 4 * g);
-                    q1 += *reinterpret_cast<const f32x4*>(bias + n0 + wn * (BN / 2) + 32 * jp + 16 + 4 * g);
+                if constexpr (EPI == 0) {
+                    q0 += bq[jp][0];
+                    q1 += bq[jp][1];
                 }
                 const unsigned off = base == 0xFFFFFF00u ? base : base + 64u * jp;
                 const u32x4 yp = pack_row8(q0, q1);
                 __builtin_amdgcn_raw_buffer_store_b128(yp, ys, off, 0, 0);
                 if constexpr (EPI == 2) {
                     // 8 consecutive columns n0 + wn * 96 + 32 jp + d0 .. of this lane's row: gelu(rounded pre-activation + fc1 bias)
-                    const float* bp = partial + n0 + wn * (BN / 2) + 32 * jp + d0;
-                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
+                    const f32x4 b0 = bq[jp][0], b1 = bq[jp][1];
                     u32x4 hp;
 #pragma unroll
                     for (int d = 0; d < 4; ++d) {
@@ -201,41 +242,45 @@ __global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_kernel(const unsigned s
             }
         }
     } else {
-        const rsrc_t as = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(aux), 0, (int)((size_t)M * N * 2), 0x00020000);
-        float csum[CT / 2][8];                        // column sums over this wave's rows: columns 32 jp + d0 + j of its 96
+        // the pre-activations were requested in the last k-step; their offsets again for the stores
+        unsigned offs[CT / 2][RT];
 #pragma unroll
         for (int jp = 0; jp < CT / 2; ++jp)
 #pragma unroll
-            for (int j = 0; j < 8; ++j) csum[jp][j] = 0.f;
-#pragma unroll
+            for (int i = 0; i < RT; ++i) offs[jp][i] = aux_off(jp, i);
+        f32x4 bv[CT / 2][2];                          // the fc1 bias of this lane's columns, loaded before the first store: a load
+#pragma unroll                                        // issued behind stores waits for them (one in-order counter)
         for (int jp = 0; jp < CT / 2; ++jp) {
             const int col8 = n0 + wn * (BN / 2) + 32 * jp + d0;
-            f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = {0.f, 0.f, 0.f, 0.f};
-            if (bias) {
-                b0 = *reinterpret_cast<const f32x4*>(bias + col8);
-                b1 = *reinterpret_cast<const f32x4*>(bias + col8 + 4);
-            }
+            bv[jp][0] = bias ? *reinterpret_cast<const f32x4*>(bias + col8) : f32x4{0.f, 0.f, 0.f, 0.f};
+            bv[jp][1] = bias ? *reinterpret_cast<const f32x4*>(bias + col8 + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        float csum[CT / 2][8];                        // column sums over this wave's rows: columns 32 jp + d0 + j of its 96
+#pragma unroll
+        for (int jp = 0; jp < CT / 2; ++jp) {
+            const f32x4 b0 = bv[jp][0], b1 = bv[jp][1];
+            float lsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};       // this lane's rows first, one cross-lane sum per column after
 #pragma unroll
             for (int i = 0; i < RT; ++i) {
-                const unsigned row = (unsigned)(m0 + wm * (BM / 2) + 16 * i + c);
-                const bool ok = row < (unsigned)M;
-                const unsigned off = ok ? row * (unsigned)(N * 2) + (unsigned)(col8 * 2) : 0xFFFFFF00u;
+                const bool ok = offs[jp][i] != 0xFFFFFF00u;
                 f32x4 q0 = acc[i][2 * jp], q1 = acc[i][2 * jp + 1];
                 exchange_row8(q0, q1);                // 8 consecutive columns col8 .. col8 + 7 of this lane's row
-                const u32x4 yv = __builtin_amdgcn_raw_buffer_load_b128(as, off, 0, 0);
                 float v[8];
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
-                    const gelu_f32x2 pre = {__builtin_bit_cast(float, yv[d] << 16) + (d < 2 ? b0[2 * d] : b1[2 * d - 4]),
-                                            __builtin_bit_cast(float, yv[d] & 0xffff0000u) + (d < 2 ? b0[2 * d + 1] : b1[2 * d - 3])};
+                    const gelu_f32x2 pre = {__builtin_bit_cast(float, yv[jp][i][d] << 16) + (d < 2 ? b0[2 * d] : b1[2 * d - 4]),
+                                            __builtin_bit_cast(float, yv[jp][i][d] & 0xffff0000u) + (d < 2 ? b0[2 * d + 1] : b1[2 * d - 3])};
                     const gelu_f32x2 gg = gelu_grad_f2(pre);
                     v[2 * d] = (d < 2 ? q0[2 * d] : q1[2 * d - 4]) * gg[0];
                     v[2 * d + 1] = (d < 2 ? q0[2 * d + 1] : q1[2 * d - 3]) * gg[1];
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(u32x4{pk2(v[0], v[1]), pk2(v[2], v[3]), pk2(v[4], v[5]), pk2(v[6], v[7])}, ys, off, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{pk2(v[0], v[1]), pk2(v[2], v[3]), pk2(v[4], v[5]), pk2(v[6], v[7])}, ys, offs[jp][i], 0, 0);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) csum[jp][j] += row16_sum(ok ? v[j] : 0.f);      // rows past M: clamped duplicates, not counted
+                for (int j = 0; j < 8; ++j) lsum[j] += ok ? v[j] : 0.f;      // rows past M: clamped duplicates, not counted
             }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) csum[jp][j] = row16_sum(lsum[j]);
         }
         __syncthreads();                              // every wave is done with the operand stages: reuse them for the column sums
         float* cs = reinterpret_cast<float*>(smem);   // [4 waves][96]
