@@ -12,6 +12,7 @@
 // Thread mapping: a row of C elements is C/4 lanes x 4 elements (16 B f32 / 8 B bf16 per lane, consecutive
 // lanes on consecutive addresses); a 256-thread block covers 256/(C/4) rows.
 #include "pswin_common.hpp"
+#include <type_traits>
 
 using namespace pswin;
 
@@ -60,6 +61,13 @@ __global__ void window_gather_kernel(const void* __restrict__ x, const int32_t* 
 // flight.  Same arithmetic, element for element, as the generic kernels.
 //   gather8:  win[b][slot] = bf16(scale_b * x[b][map[slot]])          x: f32, win: bf16   (backward of scatter_add)
 //   scatter8: out[b][t] = resid[b][t] + scale_b * (win[b][inv[t]] + bias)   win: bf16, resid / out: f32
+// Both kernels handle two rows per thread in PHASES: the map entries and everything that does not depend on them (scales,
+// residual rows) are requested for both rows at once, then the mapped rows, then the arithmetic and the stores.  Written row
+// after row, each row was a chain of up to four dependent memory round trips and the second row's loads queued behind the
+// first row's stores (one in-order counter).
+// Straight-line code (template flags instead of pointer tests, rows past the end clamped instead of skipped): a branch around a
+// load is a join where the compiler waits for everything outstanding.
+template <bool SCALE>
 __global__ __launch_bounds__(256) void window_gather8_kernel(const float* __restrict__ x, const int32_t* __restrict__ map,
                                                              const float* __restrict__ scale,
                                                              unsigned short* __restrict__ win, long long rows, int S,
@@ -67,30 +75,41 @@ __global__ __launch_bounds__(256) void window_gather8_kernel(const float* __rest
     const int lane = threadIdx.x % lanes, rl = threadIdx.x / lanes;
     if (rl >= rpb) return;
     const size_t C = (size_t)lanes * 8;
+    // blockIdx.y = image: no division, and a row index past the image's last slot is clamped for the loads and skips the store
+    const int b = blockIdx.y;
+    unsigned r[2];
+    int src[2];
+    const float sc = SCALE ? scale[b] : 1.0f;
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        const long long row = ((long long)blockIdx.x * 2 + u) * rpb + rl;
-        if (row >= rows) continue;
-        const int b = (int)(row / n_slots);
-        const int src = map[(int)(row - (long long)b * n_slots)];
-        u32x4 o = {0u, 0u, 0u, 0u};
-        if (src >= 0) {
-            const float* p = x + ((size_t)b * S + src) * C + 8 * (size_t)lane;
-            f32x4 a = *reinterpret_cast<const f32x4*>(p), c = *reinterpret_cast<const f32x4*>(p + 4);
-            if (scale) {
-                const float sc = scale[b];
-                a = a * sc;
-                c = c * sc;
-            }
-            o[0] = (unsigned)f32_to_bf16_bits(a[0]) | ((unsigned)f32_to_bf16_bits(a[1]) << 16);
-            o[1] = (unsigned)f32_to_bf16_bits(a[2]) | ((unsigned)f32_to_bf16_bits(a[3]) << 16);
-            o[2] = (unsigned)f32_to_bf16_bits(c[0]) | ((unsigned)f32_to_bf16_bits(c[1]) << 16);
-            o[3] = (unsigned)f32_to_bf16_bits(c[2]) | ((unsigned)f32_to_bf16_bits(c[3]) << 16);
-        }
-        *reinterpret_cast<u32x4*>(win + (size_t)row * C + 8 * (size_t)lane) = o;
+        r[u] = (blockIdx.x * 2u + u) * (unsigned)rpb + (unsigned)rl;
+        src[u] = map[r[u] < (unsigned)n_slots ? r[u] : (unsigned)n_slots - 1];
+    }
+    asm volatile("" : "+v"(src[0]), "+v"(src[1]));          // both map entries requested before either is used (the compiler would
+                                                            // sink a row's loads into the branch around its store)
+    f32x4 a[2], c[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const float* p = x + ((size_t)b * S + (src[u] >= 0 ? src[u] : 0)) * C + 8 * (size_t)lane;         // padding slots: any valid row
+        a[u] = *reinterpret_cast<const f32x4*>(p);
+        c[u] = *reinterpret_cast<const f32x4*>(p + 4);
+    }
+    asm volatile("" : "+v"(a[0]), "+v"(c[0]), "+v"(a[1]), "+v"(c[1]));
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const float m = src[u] >= 0 ? sc : 0.f;                                                            // padding slots are zero rows
+        const f32x4 av = (SCALE || src[u] < 0) ? a[u] * m : a[u], cv = (SCALE || src[u] < 0) ? c[u] * m : c[u];
+        u32x4 o;
+        o[0] = (unsigned)f32_to_bf16_bits(av[0]) | ((unsigned)f32_to_bf16_bits(av[1]) << 16);
+        o[1] = (unsigned)f32_to_bf16_bits(av[2]) | ((unsigned)f32_to_bf16_bits(av[3]) << 16);
+        o[2] = (unsigned)f32_to_bf16_bits(cv[0]) | ((unsigned)f32_to_bf16_bits(cv[1]) << 16);
+        o[3] = (unsigned)f32_to_bf16_bits(cv[2]) | ((unsigned)f32_to_bf16_bits(cv[3]) << 16);
+        if (src[u] < 0) o = u32x4{0u, 0u, 0u, 0u};                                                       // exact zeros (x may hold inf / nan)
+        if (r[u] < (unsigned)n_slots) *reinterpret_cast<u32x4*>(win + ((size_t)b * n_slots + r[u]) * C + 8 * (size_t)lane) = o;
     }
 }
 
+template <bool SCALE, bool RESID, bool BIAS>
 __global__ __launch_bounds__(256) void window_scatter_add8_kernel(const unsigned short* __restrict__ win,
                                                                   const int32_t* __restrict__ inv,
                                                                   const float* __restrict__ resid,
@@ -101,37 +120,56 @@ __global__ __launch_bounds__(256) void window_scatter_add8_kernel(const unsigned
     if (rl >= rpb) return;
     const size_t C = (size_t)lanes * 8;
     f32x4 b0 = {0.f, 0.f, 0.f, 0.f}, b1 = b0;
-    if (bias) {
+    if constexpr (BIAS) {
         b0 = *reinterpret_cast<const f32x4*>(bias + 8 * lane);
         b1 = *reinterpret_cast<const f32x4*>(bias + 8 * lane + 4);
     }
+    // blockIdx.y = image: no division, and a token index past the image's last token is clamped for the loads and skips the store
+    const int b = blockIdx.y;
+    unsigned t[2], tc[2];
+    int slot[2];
+    const float sc = SCALE ? scale[b] : 1.0f;
+    f32x4 r0[2], r1[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-        const long long row = ((long long)blockIdx.x * 2 + u) * rpb + rl;
-        if (row >= rows) continue;
-        const int b = (int)(row / S);
-        const int slot = inv[(int)(row - (long long)b * S)];
-        const u32x4 raw = *reinterpret_cast<const u32x4*>(win + ((size_t)b * n_slots + slot) * C + 8 * (size_t)lane);
-        f32x4 a = {__builtin_bit_cast(float, raw[0] << 16), __builtin_bit_cast(float, raw[0] & 0xffff0000u),
-                   __builtin_bit_cast(float, raw[1] << 16), __builtin_bit_cast(float, raw[1] & 0xffff0000u)};
-        f32x4 c = {__builtin_bit_cast(float, raw[2] << 16), __builtin_bit_cast(float, raw[2] & 0xffff0000u),
-                   __builtin_bit_cast(float, raw[3] << 16), __builtin_bit_cast(float, raw[3] & 0xffff0000u)};
-        if (bias) {
+        t[u] = (blockIdx.x * 2u + u) * (unsigned)rpb + (unsigned)rl;
+        tc[u] = t[u] < (unsigned)S ? t[u] : (unsigned)S - 1;
+        slot[u] = inv[tc[u]];
+        r0[u] = r1[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (RESID) {
+            const size_t o = ((size_t)b * S + tc[u]) * C + 8 * (size_t)lane;
+            r0[u] = *reinterpret_cast<const f32x4*>(resid + o);
+            r1[u] = *reinterpret_cast<const f32x4*>(resid + o + 4);
+        }
+    }
+    asm volatile("" : "+v"(slot[0]), "+v"(slot[1]));        // both map entries (and the residual rows) requested before either is used
+    u32x4 raw[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) raw[u] = *reinterpret_cast<const u32x4*>(win + ((size_t)b * n_slots + slot[u]) * C + 8 * (size_t)lane);
+    asm volatile("" : "+v"(raw[0]), "+v"(raw[1]), "+v"(r0[0]), "+v"(r1[0]), "+v"(r0[1]), "+v"(r1[1]));
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        f32x4 a = {__builtin_bit_cast(float, raw[u][0] << 16), __builtin_bit_cast(float, raw[u][0] & 0xffff0000u),
+                   __builtin_bit_cast(float, raw[u][1] << 16), __builtin_bit_cast(float, raw[u][1] & 0xffff0000u)};
+        f32x4 c = {__builtin_bit_cast(float, raw[u][2] << 16), __builtin_bit_cast(float, raw[u][2] & 0xffff0000u),
+                   __builtin_bit_cast(float, raw[u][3] << 16), __builtin_bit_cast(float, raw[u][3] & 0xffff0000u)};
+        if constexpr (BIAS) {
             a = a + b0;
             c = c + b1;
         }
-        if (scale) {
-            const float sc = scale[b];
+        if constexpr (SCALE) {
             a = a * sc;
             c = c * sc;
         }
-        const size_t o = (size_t)row * C + 8 * (size_t)lane;
-        if (resid) {
-            a = a + *reinterpret_cast<const f32x4*>(resid + o);
-            c = c + *reinterpret_cast<const f32x4*>(resid + o + 4);
+        if constexpr (RESID) {
+            a = a + r0[u];
+            c = c + r1[u];
         }
-        *reinterpret_cast<f32x4*>(out + o) = a;
-        *reinterpret_cast<f32x4*>(out + o + 4) = c;
+        if (t[u] < (unsigned)S) {
+            const size_t o = ((size_t)b * S + t[u]) * C + 8 * (size_t)lane;
+            *reinterpret_cast<f32x4*>(out + o) = a;
+            *reinterpret_cast<f32x4*>(out + o + 4) = c;
+        }
     }
 }
 
@@ -257,10 +295,15 @@ extern "C" int pswin_window_gather(const void* x, int x_dtype, const int32_t* ma
     RowGeom g = row_geom(C);
     long long rows = (long long)B * n_slots;
     PSWIN_CHECK_ARG(rows_ok(rows, g.rows_per_block));
-    if (x_dtype == PSWIN_F32 && win_dtype == PSWIN_BF16 && C / 8 <= 256) {
+    if (x_dtype == PSWIN_F32 && win_dtype == PSWIN_BF16 && C / 8 <= 256 && B <= 65535) {
         const int lanes = C / 8, rpb = 256 / lanes;
-        hipLaunchKernelGGL(window_gather8_kernel, dim3((unsigned)((rows + 2 * rpb - 1) / (2 * rpb))), dim3(256), 0,
-                           (hipStream_t)stream, (const float*)x, map, scale, (unsigned short*)win, rows, S, n_slots, lanes, rpb);
+        const dim3 grid8((unsigned)((n_slots + 2 * rpb - 1) / (2 * rpb)), (unsigned)B);
+        if (scale)
+            hipLaunchKernelGGL(window_gather8_kernel<true>, grid8, dim3(256), 0, (hipStream_t)stream, (const float*)x, map, scale,
+                               (unsigned short*)win, rows, S, n_slots, lanes, rpb);
+        else
+            hipLaunchKernelGGL(window_gather8_kernel<false>, grid8, dim3(256), 0, (hipStream_t)stream, (const float*)x, map, scale,
+                               (unsigned short*)win, rows, S, n_slots, lanes, rpb);
         PSWIN_LAUNCH_RET();
     }
     dim3 grid((unsigned)((rows + g.rows_per_block - 1) / g.rows_per_block));
@@ -280,11 +323,27 @@ extern "C" int pswin_window_scatter_add(const void* win, int win_dtype, const in
     RowGeom g = row_geom(C);
     long long rows = (long long)B * S;
     PSWIN_CHECK_ARG(rows_ok(rows, g.rows_per_block));
-    if (win_dtype == PSWIN_BF16 && x_dtype == PSWIN_F32 && C / 8 <= 256) {
+    if (win_dtype == PSWIN_BF16 && x_dtype == PSWIN_F32 && C / 8 <= 256 && B <= 65535) {
         const int lanes = C / 8, rpb = 256 / lanes;
-        hipLaunchKernelGGL(window_scatter_add8_kernel, dim3((unsigned)((rows + 2 * rpb - 1) / (2 * rpb))), dim3(256), 0,
-                           (hipStream_t)stream, (const unsigned short*)win, inv, (const float*)resid, scale, bias, (float*)out,
-                           rows, S, n_slots, lanes, rpb);
+        const dim3 grid8((unsigned)((S + 2 * rpb - 1) / (2 * rpb)), (unsigned)B);
+        auto go = [&](auto sc_, auto rs_, auto bs_) {
+            hipLaunchKernelGGL((window_scatter_add8_kernel<decltype(sc_)::value, decltype(rs_)::value, decltype(bs_)::value>), grid8, dim3(256),
+                               0, (hipStream_t)stream, (const unsigned short*)win, inv, (const float*)resid, scale, bias, (float*)out,
+                               rows, S, n_slots, lanes, rpb);
+        };
+        using T = std::true_type;
+        using F = std::false_type;
+        const int variant = (scale ? 4 : 0) | (resid ? 2 : 0) | (bias ? 1 : 0);
+        switch (variant) {
+            case 0: go(F{}, F{}, F{}); break;
+            case 1: go(F{}, F{}, T{}); break;
+            case 2: go(F{}, T{}, F{}); break;
+            case 3: go(F{}, T{}, T{}); break;
+            case 4: go(T{}, F{}, F{}); break;
+            case 5: go(T{}, F{}, T{}); break;
+            case 6: go(T{}, T{}, F{}); break;
+            default: go(T{}, T{}, T{}); break;
+        }
         PSWIN_LAUNCH_RET();
     }
     dim3 grid((unsigned)((rows + g.rows_per_block - 1) / g.rows_per_block));
