@@ -47,6 +47,9 @@ struct AttnArgs {
     void* out;              // fwd
     const void* dout;       // bwd
     float* lse;             // fwd: written ; bwd: read
+#ifdef PSWIN_ATTN_STAMPS
+    unsigned long long* stamps;   // tools/probe/attn_probe.hip: per wave, 8 accumulated s_memtime intervals
+#endif
     void *dq, *dk, *dv;     // bwd
     float* dtab;            // bwd: [n_items][64 j][64 i] sums of dS over the item's images, or null
     int n_dist, n_mask;
@@ -67,13 +70,15 @@ struct TabRaw {
 };
 static_assert(NBINS <= 3 * 64, "three table entries per lane");
 __device__ inline TabRaw tables_fetch(const AttnArgs& a, int h, int lane) {
+    // buffer loads: entries past the table and the alpha column of a planar layer (no distance tiles) read as 0, no branches
+    const __amdgpu_buffer_rsrc_t bres = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.beta), 0, NBINS * a.heads * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ares = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.alpha), 0, a.dist ? NBINS * a.heads * 4 : 0, 0x00020000);
     TabRaw r;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const int t = lane + 64 * k;
-        const bool ok = t < NBINS;
-        r.b[k] = ok ? a.beta[t * a.heads + h] : 0.f;
-        r.a[k] = (ok && a.dist) ? a.alpha[t * a.heads + h] : 0.f;
+        const int off = ((lane + 64 * k) * a.heads + h) * 4;
+        r.b[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(bres, off, 0, 0));
+        r.a[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ares, off, 0, 0));
     }
     return r;
 }
@@ -171,11 +176,16 @@ __global__ __launch_bounds__(64 * WAVES, (DT == PSWIN_BF16 ? (NQ == 2 ? 3 : 2) :
         __builtin_amdgcn_sched_barrier(0);
         tables_store(tabs, lane, tab_a, tab_b);
         __builtin_amdgcn_wave_barrier();
+        // table lookups two quads at a time (all 8 at once would cost this kernel its third wave per SIMD)
 #pragma unroll
         for (int tq = 0; tq < NQ; ++tq)
 #pragma unroll
-            for (int tj = 0; tj < 4; ++tj)
-                bias[tq][tj] = bias_from<false>(raw[tq][tj], dtile, mtile, tab_a, tab_b, 16 * (ti0 + tq) + c, 16 * tj + 4 * g, inv_scale);
+            for (int tj = 0; tj < 4; tj += 2) {
+                const BiasTab t0 = bias_lookup<false>(tab_a, tab_b, 16 * (ti0 + tq) + c, 16 * tj + 4 * g);
+                const BiasTab t1 = bias_lookup<false>(tab_a, tab_b, 16 * (ti0 + tq) + c, 16 * (tj + 1) + 4 * g);
+                bias[tq][tj] = bias_from<false>(raw[tq][tj], t0, 16 * (ti0 + tq) + c, 16 * tj + 4 * g, inv_scale);
+                bias[tq][tj + 1] = bias_from<false>(raw[tq][tj + 1], t1, 16 * (ti0 + tq) + c, 16 * (tj + 1) + 4 * g, inv_scale);
+            }
     }
 
     for (int r = 0; r < a.reps_per_chunk; ++r) {
@@ -332,7 +342,8 @@ __global__ __launch_bounds__(64 * WAVES) void attn_bwd_kernel(AttnArgs a) {
         for (int ti = 0; ti < 4; ++ti)
 #pragma unroll
             for (int tj = 0; tj < 4; ++tj)
-                bias[ti][tj] = bias_from<true>(raw[ti][tj], dtile, mtile, tab_a, tab_b, 16 * ti + 4 * g, 16 * tj + c, inv_scale);
+                bias[ti][tj] = bias_from<true>(raw[ti][tj], bias_lookup<true>(tab_a, tab_b, 16 * ti + 4 * g, 16 * tj + c), 16 * ti + 4 * g, 16 * tj + c,
+                                               inv_scale);
     }
 
     f32x4 gsum[4][4];   // sum over the batch loop of dS
@@ -508,8 +519,21 @@ __device__ inline Frag<PSWIN_BF16> tr32(const char* img, int R0, int col0, int c
     return f;
 }
 
+#ifdef PSWIN_ATTN_STAMPS
+#define PSWIN_STAMP(i)                                                  \
+    do {                                                                \
+        const unsigned long long t_ = __builtin_amdgcn_s_memtime();     \
+        stamp_acc[i] += t_ - stamp_last;                                \
+        stamp_last = t_;                                                \
+    } while (0)
+#else
+#define PSWIN_STAMP(i)
+#endif
 __global__ __launch_bounds__(128, 2) void attn_bwd_pair_kernel(AttnArgs a) {
     constexpr int DT = PSWIN_BF16;
+#ifdef PSWIN_ATTN_STAMPS
+    unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, stamp_last = __builtin_amdgcn_s_memtime();
+#endif
     __shared__ __attribute__((aligned(16))) char smem[PairLds::BYTES];
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;      // w = query half
     const int c = lane & 15, g = lane >> 4;
@@ -586,15 +610,22 @@ __global__ __launch_bounds__(128, 2) void attn_bwd_pair_kernel(AttnArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         if (w == 0) tables_store(tabs, lane, tab_a, tab_b);
         __syncthreads();
+        BiasTab tab[2][4];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+            for (int tj = 0; tj < 4; ++tj) tab[tt][tj] = bias_lookup<true>(tab_a, tab_b, 16 * (2 * w + tt) + 4 * g, 16 * tj + c);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
             for (int tj = 0; tj < 4; ++tj) {
-                bias[tt][tj] = bias_from<true>(raw[tt][tj], dtile, mtile, tab_a, tab_b, 16 * (2 * w + tt) + 4 * g, 16 * tj + c, inv_scale);
+                bias[tt][tj] = bias_from<true>(raw[tt][tj], tab[tt][tj], 16 * (2 * w + tt) + 4 * g, 16 * tj + c, inv_scale);
                 gsum[tt][tj] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
     }
 
+    PSWIN_STAMP(0);
     for (int r = 0; r < a.reps_per_chunk; ++r) {
         const size_t win = (size_t)(chunk * a.reps_per_chunk + r) * a.nb + wb;
         const size_t row0 = win * TOK;
@@ -649,6 +680,7 @@ __global__ __launch_bounds__(128, 2) void attn_bwd_pair_kernel(AttnArgs a) {
                 dsf[tj] = pack_frag<DT>(ds4[0][tj], ds4[1][tj]);
             }
         }
+        PSWIN_STAMP(1);
         // operands consumed: request the next image
         if (r + 1 < a.reps_per_chunk) load_ops(r + 1, cur);
 
@@ -674,7 +706,9 @@ __global__ __launch_bounds__(128, 2) void attn_bwd_pair_kernel(AttnArgs a) {
                     *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(exch) + exch_off(16 * tj + c, 4 * dt + g)) = w == 0 ? dkp : dvp;
                 }
         }
+        PSWIN_STAMP(2);
         __syncthreads();          // exchange written, K image written
+        PSWIN_STAMP(3);
         {
             const float* other = w == 0 ? exch_dv : exch_dk;
             const rsrc_t dst = window_rsrc<DT>(w == 0 ? a.dv : a.dk, dhead0, a.ld_dqkv);
@@ -688,6 +722,7 @@ __global__ __launch_bounds__(128, 2) void attn_bwd_pair_kernel(AttnArgs a) {
                 store_row8_at<DT>(dst, dkv_off[tj], g, o0, o1);
             }
         }
+        PSWIN_STAMP(4);
         // dQ^T[d][i] = scale * sum_j K^T[d][j] dS^T[j][i] for this wave's queries
         f32x4 dq[2][2];
 #pragma unroll
@@ -710,8 +745,14 @@ __global__ __launch_bounds__(128, 2) void attn_bwd_pair_kernel(AttnArgs a) {
         for (int tt = 0; tt < 2; ++tt) {
             store_row8_at<DT>(window_rsrc<DT>(a.dq, dhead0, a.ld_dqkv), dq_off[tt], g, dq[0][tt] * a.scale, dq[1][tt] * a.scale);
         }
+        PSWIN_STAMP(5);
         __syncthreads();          // both waves are done with the K image and the exchange buffers
+        PSWIN_STAMP(6);
     }
+#ifdef PSWIN_ATTN_STAMPS
+    if (a.stamps && lane == 0)
+        for (int i = 0; i < 8; ++i) a.stamps[((size_t)blockIdx.x * 2 + w) * 8 + i] = stamp_acc[i];
+#endif
     if (a.dtab) {
         float* gt = a.dtab + (size_t)item * (PADT * PADT);
 #pragma unroll
@@ -942,6 +983,11 @@ extern "C" int pswin_attn_table_grads_workspace(int heads) {
     return heads > 0 ? (DTAB_BLOCKS + 1) * dtab_ld(heads) : PSWIN_ERR_ARG;   // block partial rows + their sum
 }
 
+#ifdef PSWIN_ATTN_STAMPS
+static unsigned long long* g_attn_stamps = nullptr;
+extern "C" void pswin_attn_debug_stamps(unsigned long long* p) { g_attn_stamps = p; }
+#endif
+
 extern "C" int pswin_attn_bwd_ex(const void* q, const void* k, const void* v, int ld_qkv, long long qkv_window_stride,
                                  int qkv_head_stride, const float* dist_t, int n_dist, const float* alpha, const float* beta,
                                  const float* mask_t, int n_mask, const void* dout, int ld_out, const float* lse, void* dq, void* dk,
@@ -965,6 +1011,9 @@ extern "C" int pswin_attn_bwd_ex(const void* q, const void* k, const void* v, in
     a.n_dist = dist_t ? n_dist : 1; a.n_mask = mask_t ? n_mask : 1;
     a.dout = dout; a.lse = const_cast<float*>(lse);
     a.dq = dq; a.dk = dk; a.dv = dv; a.dtab = dscore_sum;
+#ifdef PSWIN_ATTN_STAMPS
+    a.stamps = g_attn_stamps;
+#endif
     a.ld_qkv = ld_qkv; a.ld_out = ld_out; a.ld_dqkv = ld_dqkv;
     a.qkv_win_stride = qkv_window_stride; a.qkv_head_stride = qkv_head_stride;
     a.nb = n_bias_windows; a.heads = heads; a.reps_per_chunk = reps / n_chunks;

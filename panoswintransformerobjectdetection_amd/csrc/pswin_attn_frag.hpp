@@ -299,31 +299,54 @@ __device__ inline int rel_b(int j) { return 13 * (j / PSWIN_WS) + j % PSWIN_WS; 
 struct BiasRaw {
     f32x4 d, m;
 };
+// Buffer loads: a null tile is a resource of zero records (the loads return 0: no branch around them) and the per-lane address
+// is one 32-bit offset -- with 64-bit pointers the register allocator reused a pending load's destination for the next address
+// and the kernel waited for memory in the middle of its request burst.
+__device__ inline __amdgpu_buffer_rsrc_t tile_rsrc(const float* tile) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(tile), 0, tile ? PADT * PADT * 4 : 0, 0x00020000);
+}
 template <bool QUERY_ON_REGS>
-__device__ inline BiasRaw bias_fetch(const float* dtile, const float* mtile, int qi, int kj) {
+__device__ inline BiasRaw bias_fetch(__amdgpu_buffer_rsrc_t dres, __amdgpu_buffer_rsrc_t mres, int qi, int kj) {
     const int row = QUERY_ON_REGS ? kj : qi, col = QUERY_ON_REGS ? qi : kj;
     BiasRaw r;
-    r.d = f32x4{0.f, 0.f, 0.f, 0.f};
-    r.m = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (dtile) r.d = *reinterpret_cast<const f32x4*>(dtile + row * PADT + col);
-    if (mtile) r.m = *reinterpret_cast<const f32x4*>(mtile + row * PADT + col);
+    r.d = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(dres, (row * PADT + col) * 4, 0, 0));
+    r.m = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(mres, (row * PADT + col) * 4, 0, 0));
     return r;
 }
 template <bool QUERY_ON_REGS>
-__device__ inline f32x4 bias_from(const BiasRaw& raw, const float* dtile, const float* mtile, const float* tab_a, const float* tab_b,
-                                  int qi, int kj, float inv_scale) {
-    const f32x4 d4 = raw.d, m4 = raw.m;
-    f32x4 r;
+__device__ inline BiasRaw bias_fetch(const float* dtile, const float* mtile, int qi, int kj) {
+    return bias_fetch<QUERY_ON_REGS>(tile_rsrc(dtile), tile_rsrc(mtile), qi, kj);
+}
+// the table entries of a quad: 4 (alpha, beta) pairs out of the LDS copy of the head's table columns.  Read for ALL quads of a
+// kernel before the first is combined (bias_lookup, then bias_from): looked up inside the arithmetic, the 32-64 lookups of a
+// work item were as many LDS round trips in a row
+struct BiasTab {
+    f32x4 a, b;
+};
+template <bool QUERY_ON_REGS>
+__device__ inline BiasTab bias_lookup(const float* tab_a, const float* tab_b, int qi, int kj) {
+    BiasTab t;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int i = QUERY_ON_REGS ? qi + e : qi, j = QUERY_ON_REGS ? kj : kj + e;
         const bool real = (i < TOK) & (j < TOK);
         int idx = rel_a(i) - rel_b(j);
         idx = real ? idx : 0;
-        // same rounding sequence as the reference: (d * alpha + beta) [+ mask]   (HOT:255-256, 294, 301)
-        float val = tab_b[idx];
-        if (dtile) val = __fadd_rn(__fmul_rn(d4[e], tab_a[idx]), val);
-        if (mtile) val = __fadd_rn(val, m4[e]);
+        t.a[e] = tab_a[idx];
+        t.b[e] = tab_b[idx];
+    }
+    return t;
+}
+template <bool QUERY_ON_REGS>
+__device__ inline f32x4 bias_from(const BiasRaw& raw, const BiasTab& tab, int qi, int kj, float inv_scale) {
+    f32x4 r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int i = QUERY_ON_REGS ? qi + e : qi, j = QUERY_ON_REGS ? kj : kj + e;
+        // same rounding sequence as the reference: (d * alpha + beta) [+ mask]   (HOT:255-256, 294, 301).  No branches: without
+        // a distance tile d = 0 and the staged alpha column is 0 (0 * 0 + beta = beta), without a mask tile m = 0.
+        float val = __fadd_rn(__fmul_rn(raw.d[e], tab.a[e]), tab.b[e]);
+        val = __fadd_rn(val, raw.m[e]);
         val *= inv_scale;
         val = (i < TOK) ? val : 0.f;                 // padded query row: discarded
         r[e] = (j < TOK) ? val : -INFINITY;          // padded key: never receives weight
@@ -333,6 +356,7 @@ __device__ inline f32x4 bias_from(const BiasRaw& raw, const float* dtile, const 
 template <bool QUERY_ON_REGS>
 __device__ inline f32x4 bias_quad(const float* dtile, const float* mtile, const float* tab_a, const float* tab_b,
                                   int qi, int kj, float inv_scale) {
-    return bias_from<QUERY_ON_REGS>(bias_fetch<QUERY_ON_REGS>(dtile, mtile, qi, kj), dtile, mtile, tab_a, tab_b, qi, kj, inv_scale);
+    return bias_from<QUERY_ON_REGS>(bias_fetch<QUERY_ON_REGS>(dtile, mtile, qi, kj), bias_lookup<QUERY_ON_REGS>(tab_a, tab_b, qi, kj), qi, kj,
+                                    inv_scale);
 }
 }  // namespace
