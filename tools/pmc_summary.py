@@ -16,8 +16,13 @@ from collections import defaultdict
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 
 KERNELS = {"win_fused_fwd_kernel": "pswin_win_attn_fused_fwd", "attn_fwd_kernel": "pswin_attn_fwd", "attn_bwd_kernel": "pswin_attn_bwd_ex", "attn_bwd_pair_kernel": "pswin_attn_bwd_ex", "ln_fwd_kernel": "pswin_ln_gather_fwd",
-           "ln_bwd_kernel": "pswin_ln_gather_bwd", "window_gather_kernel": "pswin_window_gather",
-           "window_scatter_add_kernel": "pswin_window_scatter_add"}
+           "ln_bwd_kernel": "pswin_ln_gather_bwd", "window_gather_kernel": "pswin_window_gather", "window_gather8_kernel": "pswin_window_gather",
+           "window_scatter_add_kernel": "pswin_window_scatter_add", "window_scatter_add8_kernel": "pswin_window_scatter_add",
+           "ln_add_fwd_kernel": "pswin_scatter_add_ln_fwd",
+           # the tiled GEMM by epilogue (template arguments <rows, EPI>): plain, fused GELU backward, fused GELU forward
+           "gemm_nt_kernel<64, 0>": "pswin_gemm_nt", "gemm_nt_kernel<128, 0>": "pswin_gemm_nt",
+           "gemm_nt_kernel<64, 1>": "pswin_gemm_nt_gelu_bwd", "gemm_nt_kernel<128, 1>": "pswin_gemm_nt_gelu_bwd",
+           "gemm_nt_kernel<64, 2>": "pswin_gemm_nt_gelu_fwd", "gemm_nt_kernel<128, 2>": "pswin_gemm_nt_gelu_fwd"}
 
 
 def collect(path, counter):
