@@ -160,6 +160,11 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs MI355X GPUs"
     dev = torch.device("cuda", local_rank if args.device is None else args.device)
     torch.cuda.set_device(dev)
+    # Everything from here on -- parameter allocation, warm-up, capture, replay launches of uncaptured work -- runs on ONE side
+    # stream: autograd's AccumulateGrad nodes remember the stream they were created on, and a node created on the default
+    # stream makes the capturing backward pass synchronise with it (torch warns; harmless here, but a needless cross-stream edge)
+    cap_stream = torch.cuda.Stream()
+    torch.cuda.set_stream(cap_stream)
     _lib.load()                                  # fail loudly if the HIP library is missing
 
     torch.manual_seed(0)
@@ -242,7 +247,7 @@ def main():
         step = eager_step
     elif split:
         from panoswintransformerobjectdetection_amd.graph import GraphedCallable, GraphedSequence
-        seq = GraphedSequence([phase1, phase2], warmup=2)
+        seq = GraphedSequence([phase1, phase2], warmup=2, stream=cap_stream)
         g_opt = GraphedCallable(opt.step, warmup=1, stream=seq.stream)
         late_buckets = reducer.buckets_within(late_params)
 
@@ -257,7 +262,7 @@ def main():
         # One hipGraph for forward+backward, one for the optimizer; the RCCL all-reduce of the flat gradient buffer
         # runs between the two replays (N > 1), so collectives are never part of a captured graph.
         from panoswintransformerobjectdetection_amd.graph import GraphedCallable
-        g_fb = GraphedCallable(fwd_bwd, warmup=2)
+        g_fb = GraphedCallable(fwd_bwd, warmup=2, stream=cap_stream)
         g_opt = GraphedCallable(opt.step, warmup=1, stream=g_fb.stream)
 
         def step():
@@ -421,6 +426,8 @@ def main_maskrcnn(args):
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run"
     dev = torch.device("cuda", local_rank if args.device is None else args.device)
     torch.cuda.set_device(dev)
+    cap_stream = torch.cuda.Stream()             # one stream for allocation, warm-up, capture and replay (see main())
+    torch.cuda.set_stream(cap_stream)
     _lib.load()
     batch = 2 if args.batch == 8 else args.batch          # configs[3]: batch = 2 per GPU
     H = args.height
@@ -456,7 +463,7 @@ def main_maskrcnn(args):
         red.pack_grads()
         return gbuf[0]
 
-    seq = GraphedSequence([phase_fwd, phase_bwd], warmup=2)
+    seq = GraphedSequence([phase_fwd, phase_bwd], warmup=2, stream=cap_stream)
     g_opt = GraphedCallable(opt_bb.step, warmup=1, stream=seq.stream)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
     parts = []
