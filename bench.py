@@ -60,7 +60,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md; ~6.3 TB
 MFMA_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 TIMED = ("pswin_win_attn_fused_fwd", "pswin_attn_fwd", "pswin_attn_bwd", "pswin_attn_bwd_ex", "pswin_window_gather", "pswin_window_scatter_add",
          "pswin_scatter_add_ln_fwd", "pswin_ln_gather_fwd", "pswin_ln_gather_bwd", "pswin_bias_gelu_fwd", "pswin_bias_gelu_bwd",
-         "pswin_gemm_skinny", "pswin_gemm_nt", "pswin_gemm_nt_gelu_fwd", "pswin_gemm_nt_gelu_bwd", "pswin_gemm_tn", "pswin_fc1_gelu_fwd", "pswin_fc1_gelu_bwd", "pswin_stem_conv2_fwd", "pswin_stem_conv3_fwd",
+         "pswin_adamw_flat", "pswin_gemm_skinny", "pswin_gemm_nt", "pswin_gemm_nt_gelu_fwd", "pswin_gemm_nt_gelu_bwd", "pswin_gemm_tn", "pswin_fc1_gelu_fwd", "pswin_fc1_gelu_bwd", "pswin_stem_conv2_fwd", "pswin_stem_conv3_fwd",
          "pswin_stem_conv3_bwd_stats", "pswin_stem_conv3_bwd_data", "pswin_stem_conv3_wgrad", "pswin_stem_conv2_wgrad",
          "pswin_stem_conv2_bwd", "lib_gemm_fwd", "lib_gemm_dgrad", "lib_gemm_wgrad")
 # hardware MFMA-pipe utilisation of the window-attention kernels: SQ_VALU_MFMA_BUSY_CYCLES of a separate rocprofv3 --pmc pass
@@ -136,6 +136,7 @@ def main():
     ap.add_argument("--eager", action="store_true", help="do not capture the step into a HIP graph")
     ap.add_argument("--model", default="T", choices=["T", "S"], help="PanoSwin-T (depths 2-2-6-2, the headline) or -S (2-2-18-2)")
     ap.add_argument("--height", type=int, default=512, help="panorama height; width = 2 * height (headline: 512)")
+    ap.add_argument("--torch-adamw", action="store_true", help="torch.optim.AdamW(fused=True) instead of the one-launch HIP update (A/B)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); 'gloo' lets two "
                     "ranks rehearse the N > 1 code path on one GPU together with --device")
     ap.add_argument("--device", type=int, default=None, help="force this HIP device index for every rank (rehearsal only)")
@@ -184,8 +185,12 @@ def main():
     # configs/swin/*.py, stated in the bench line: their paramwise_cfg sets decay_mult = 0 for 'norm' parameters (and for two key
     # patterns this model does not have); same arithmetic per element and same cost, different decay on 0.2 % of the elements.
     opt_params = [reducer.flatten_parameters(model, cd if cd != torch.float32 else None)] if not args.eager else list(model.parameters())
-    opt = torch.optim.AdamW(opt_params, lr=1e-4, betas=(0.9, 0.999), weight_decay=0.05, fused=True,
-                            capturable=not args.eager)
+    if args.eager or args.torch_adamw:
+        opt = torch.optim.AdamW(opt_params, lr=1e-4, betas=(0.9, 0.999), weight_decay=0.05, fused=True, capturable=not args.eager)
+    else:
+        # the update of the flat buffer and the bf16 copy of the new weights in one HIP launch (the arithmetic of torch.optim.AdamW)
+        from panoswintransformerobjectdetection_amd.optim import FlatAdamW
+        opt = FlatAdamW(opt_params[0], lr=1e-4, betas=(0.9, 0.999), weight_decay=0.05, model=model if cd != torch.float32 else None)
 
     torch.manual_seed(1234 + rank)               # every rank its own shard of synthetic panoramas
     x = torch.randn(args.batch, 3, args.height, 2 * args.height, device=dev)

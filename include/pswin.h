@@ -311,6 +311,14 @@ typedef struct pswin_transpose_job {
 /* dst = src^T for every job in one launch (rows, cols multiples of 64): the per-step [K][N] bf16 copies of the Linear
  * weights with which pswin_gemm_nt computes data gradients.  `jobs` is a HOST array, copied into the kernel arguments. */
 int pswin_transpose_jobs(const pswin_transpose_job* jobs, int n_jobs, void* stream);
+
+/* AdamW over the one flat fp32 parameter buffer of a model: the update that ends every training step of the path (the reference runs
+ * torch.optim.AdamW through mmcv's OptimizerHook, mmdet/apis/train.py:91-112 with configs/swin/*.py: lr 1e-4, betas (0.9, 0.999),
+ * weight_decay 0.05), fused with the bf16 copy of the updated parameters that the next step's kernels read.  p, g, m, v: f32 [n]
+ * (n a multiple of 4, 16-byte aligned); p_bf16: bf16 [n] or NULL; step: DEVICE pointer to the number (>= 1, as a float) of the step being
+ * taken.  Same arithmetic, element by element, as torch.optim.AdamW. */
+int pswin_adamw_flat(float* p, const float* g, float* m, float* v, void* p_bf16, long long n, double lr, double beta1, double beta2, double eps,
+                     double weight_decay, const float* step, void* stream);
 int pswin_gemm_nt_supported(long long M, int K, int N);
 int pswin_gemm_nt(const void* x, const void* w, const float* bias, void* y, long long M, int K, int N, int tile_m, void* stream);
 /* The data gradient of the Mlp's fc2 fused with the backward of fc1's bias + nn.GELU (HOT:50-58):

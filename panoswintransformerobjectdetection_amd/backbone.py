@@ -486,7 +486,8 @@ class SimplePanoSwinTransformer(nn.Module, DoubleModeModule):
         (instead of ~100 small cast kernels); plain attributes, never part of the state dict."""
         fp = self.__dict__.get("_flat_pair")
         if fp is not None and fp[1].dtype == cd:
-            fp[1].copy_(fp[0])                      # every master weight -> its low-precision view, one kernel
+            if not self.__dict__.get("_lowp_external"):     # (optim.FlatAdamW writes the copy with the update itself)
+                fp[1].copy_(fp[0])                  # every master weight -> its low-precision view, one kernel
             if for_backward:
                 self._refresh_transposed(cd)
             return

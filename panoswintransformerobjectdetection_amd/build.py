@@ -12,7 +12,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libpswin_hip.so")
-SOURCES = ["pswin_index.hip", "pswin_geom.hip", "pswin_move.hip", "pswin_attn.hip", "pswin_norm.hip", "pswin_bn.hip", "pswin_stem.hip", "pswin_mlp.hip", "pswin_gemm.hip", "pswin_gemm_nt.hip", "pswin_gemm_tn.hip", "pswin_fused.hip"]
+SOURCES = ["pswin_index.hip", "pswin_geom.hip", "pswin_move.hip", "pswin_attn.hip", "pswin_norm.hip", "pswin_bn.hip", "pswin_stem.hip", "pswin_mlp.hip", "pswin_gemm.hip", "pswin_gemm_nt.hip", "pswin_gemm_tn.hip", "pswin_fused.hip", "pswin_optim.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]

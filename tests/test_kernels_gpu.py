@@ -887,3 +887,31 @@ def test_fc1_with_the_gelu_in_its_epilogue(ops, M, C, tile):
         assert torch.allclose(u, v, rtol=2e-2, atol=2e-2 * float(v.abs().max())), (u - v).abs().max()
     with torch.no_grad():
         assert torch.equal(ops.mlp_fused(x, fc1, fc2), a[0].to(torch.bfloat16))
+
+
+def test_flat_adamw_matches_torch_adamw(ops):
+    """optim.FlatAdamW (pswin_adamw_flat: one launch over the flat parameter buffer, bf16 copy of the new weights in the same pass)
+    against torch.optim.AdamW on the same gradients for 6 steps: parameters and both moments to f32 rounding, the bf16 shadow
+    exactly bf16(parameters)."""
+    from panoswintransformerobjectdetection_amd.optim import FlatAdamW
+    torch.manual_seed(7)
+    n = 4 * 100003
+    p0 = torch.randn(n, device=DEV)
+    ref = torch.nn.Parameter(p0.clone())
+    mine = torch.nn.Parameter(p0.clone())
+    kw = dict(lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05)
+    o_ref = torch.optim.AdamW([ref], **kw)
+    o_mine = FlatAdamW(mine, **kw)
+    shadow = torch.empty(n, dtype=torch.bfloat16, device=DEV)
+    o_mine.lowp = shadow
+    for step in range(6):
+        g = torch.randn(n, device=DEV) * (0.1 + step)
+        ref.grad, mine.grad = g.clone(), g.clone()
+        o_ref.step()
+        o_mine.step()
+        assert torch.allclose(mine.data, ref.data, rtol=2e-6, atol=2e-7), (step, (mine.data - ref.data).abs().max())
+        assert torch.equal(shadow, mine.data.to(torch.bfloat16))
+    st = o_ref.state[ref]
+    assert torch.allclose(o_mine.exp_avg, st["exp_avg"], rtol=1e-5, atol=1e-6)            # (sums with cancellation: absolute bound)
+    assert torch.allclose(o_mine.exp_avg_sq, st["exp_avg_sq"], rtol=1e-5, atol=1e-8)
+    assert float(o_mine.step_t) == 6.0
