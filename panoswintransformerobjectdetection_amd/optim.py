@@ -23,9 +23,10 @@ class FlatAdamW(torch.optim.Optimizer):
             raise PswinError("FlatAdamW: the flat buffer must live on the GPU and hold a multiple of 4 elements")
         super().__init__([flat_param], dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.flat = flat_param
-        self.exp_avg = torch.zeros_like(flat_param.data)
-        self.exp_avg_sq = torch.zeros_like(flat_param.data)
-        self.step_t = torch.zeros(1, dtype=torch.float32, device=flat_param.device)      # steps taken so far
+        # the state lives where torch.optim.AdamW(capturable=True) keeps it, under the same keys: state_dict() / load_state_dict()
+        # of the two optimizers are interchangeable for the flat parameter
+        self.state[flat_param] = dict(step=torch.zeros((), dtype=torch.float32, device=flat_param.device),      # steps taken so far
+                                      exp_avg=torch.zeros_like(flat_param.data), exp_avg_sq=torch.zeros_like(flat_param.data))
         self.lowp = None
         pair = None if model is None else model.__dict__.get("_flat_pair")
         if pair is not None:
@@ -34,6 +35,10 @@ class FlatAdamW(torch.optim.Optimizer):
             self.lowp = pair[1]
             self.lowp.copy_(flat_param.data)             # in step with the weights before the first forward pass
             model.__dict__["_lowp_external"] = True      # backbone._refresh_lowp: the shadow is kept fresh here
+
+    exp_avg = property(lambda self: self.state[self.flat]["exp_avg"])
+    exp_avg_sq = property(lambda self: self.state[self.flat]["exp_avg_sq"])
+    step_t = property(lambda self: self.state[self.flat]["step"])
 
     @torch.no_grad()
     def sync_lowp(self):
@@ -51,7 +56,10 @@ class FlatAdamW(torch.optim.Optimizer):
         if g.dtype != torch.float32 or not g.is_contiguous() or g.numel() != self.flat.numel():
             raise PswinError("FlatAdamW: the gradient must be the flat fp32 gradient buffer")
         grp = self.param_groups[0]
-        self.step_t += 1.0
+        st = self.state[self.flat]
+        if st["step"].dtype != torch.float32 or not st["step"].is_cuda:                   # (a state dict saved by torch's non-capturable AdamW)
+            st["step"] = torch.as_tensor(float(st["step"]), dtype=torch.float32, device=self.flat.device)
+        st["step"] += 1.0
         call("pswin_adamw_flat", self.flat, ptr(self.flat.data), ptr(g), ptr(self.exp_avg), ptr(self.exp_avg_sq), ptr(self.lowp),
              self.flat.numel(), float(grp["lr"]), float(grp["betas"][0]), float(grp["betas"][1]), float(grp["eps"]),
              float(grp["weight_decay"]), ptr(self.step_t),

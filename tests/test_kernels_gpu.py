@@ -915,3 +915,27 @@ def test_flat_adamw_matches_torch_adamw(ops):
     assert torch.allclose(o_mine.exp_avg, st["exp_avg"], rtol=1e-5, atol=1e-6)            # (sums with cancellation: absolute bound)
     assert torch.allclose(o_mine.exp_avg_sq, st["exp_avg_sq"], rtol=1e-5, atol=1e-8)
     assert float(o_mine.step_t) == 6.0
+
+
+def test_flat_adamw_state_dict_round_trip_with_torch_adamw(ops):
+    """The state of optim.FlatAdamW sits under torch.optim.AdamW's keys: a state dict saved by one continues in the other."""
+    from panoswintransformerobjectdetection_amd.optim import FlatAdamW
+    torch.manual_seed(11)
+    n = 4096
+    kw = dict(lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05)
+    a = torch.nn.Parameter(torch.randn(n, device=DEV))
+    b = torch.nn.Parameter(a.data.clone())
+    oa, ob = FlatAdamW(a, **kw), torch.optim.AdamW([b], capturable=True, **kw)
+    gs = [torch.randn(n, device=DEV) for _ in range(4)]
+    for g in gs[:2]:
+        a.grad, b.grad = g.clone(), g.clone()
+        oa.step(); ob.step()
+    # swap: torch continues from the HIP optimizer's state and vice versa
+    sa, sb = oa.state_dict(), ob.state_dict()
+    oa2, ob2 = FlatAdamW(a, **kw), torch.optim.AdamW([b], capturable=True, **kw)
+    oa2.load_state_dict(sb); ob2.load_state_dict(sa)
+    for g in gs[2:]:
+        a.grad, b.grad = g.clone(), g.clone()
+        oa2.step(); ob2.step()
+    assert float(oa2.step_t) == 4.0
+    assert torch.allclose(a.data, b.data, rtol=2e-6, atol=2e-7), (a.data - b.data).abs().max()
