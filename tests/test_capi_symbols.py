@@ -37,6 +37,46 @@ def test_library_exports_every_declared_symbol():
     assert lib.pswin_attn_table_grads_workspace(3) > 0
 
 
+def test_argument_errors_of_the_round_2_entry_points_without_a_gpu():
+    """Every entry point validates its arguments before it touches the device: bad calls return PSWIN_ERR_ARG (-1) on a CPU-only
+    host (the reference's operators raise on such inputs; the Python layer turns the code into PswinError)."""
+    from panoswintransformerobjectdetection_amd import _lib
+    lib = _lib.load()
+    ERR = -1
+    buf = (ctypes.c_char * 4096)()
+    p = ctypes.cast(buf, ctypes.c_void_p).value
+    p16 = (p + 15) & ~15
+    # tiled GEMM family: shape support (N a multiple of 192, K of 64, M >= 64, < 4 GB operands) and tile heights
+    assert lib.pswin_gemm_nt_supported(16384, 384, 1536) == 1 and lib.pswin_gemm_nt_supported(16384, 384, 1500) == 0
+    assert lib.pswin_gemm_nt_supported(32, 384, 1536) == 0 and lib.pswin_gemm_nt_supported(16384, 100, 1536) == 0
+    assert lib.pswin_gemm_nt(None, p16, None, p16, 16384, 384, 1536, 0, None) == ERR                      # null operand
+    assert lib.pswin_gemm_nt(p16, p16, None, p16, 16384, 384, 1536, 96, None) == ERR                      # tile height
+    assert lib.pswin_gemm_nt(p16 + 2, p16, None, p16, 16384, 384, 1536, 0, None) == ERR                   # alignment
+    assert lib.pswin_gemm_nt_gelu_fwd(p16, p16, None, p16, p16, 16384, 384, 1536, 128, None) == ERR       # fc1 bias is required
+    assert lib.pswin_gemm_nt_gelu_fwd(p16, p16, p16, p16, p16, 16384, 384, 1536, 0, None) == ERR          # explicit tile height
+    assert lib.pswin_gemm_nt_gelu_bwd(p16, p16, p16, p16, p16, None, 16384, 384, 1536, 128, None) == ERR  # partial sums buffer
+    assert lib.pswin_gemm_nt_partial_rows(16384, 128) == 128 and lib.pswin_gemm_nt_partial_rows(16385, 64) == 257
+    assert lib.pswin_gemm_nt_partial_rows(16384, 100) == ERR
+    assert lib.pswin_gemm_tn_supported(16384, 1152, 384) == 1 and lib.pswin_gemm_tn_supported(16384, 576, 192) == 0
+    assert lib.pswin_gemm_tn(p16, p16, p16, 16384, 1152, 384, 0, None) == ERR                             # splits >= 1
+    # fused window kernel: C = 96 / 3 heads / bf16 only
+    assert lib.pswin_win_attn_fused_supported(96, 3, 1) == 1 and lib.pswin_win_attn_fused_supported(192, 6, 1) == 0
+    assert lib.pswin_win_attn_fused_supported(96, 3, 0) == 0
+    # attention backward with explicit q / k / v strides: strides must cover a window and be multiples of 8 elements
+    args = [p16, p16, p16, 96, 49 * 96, 32, None, 0, None, p16, None, 0, p16, 96, p16, p16, p16, p16, 96, None, 1, 8, 8, 3, 0.1767767, 1, None]
+    bad = list(args); bad[4] = 48 * 96
+    assert lib.pswin_attn_bwd_ex(*bad) == ERR
+    bad = list(args); bad[5] = 30
+    assert lib.pswin_attn_bwd_ex(*bad) == ERR
+    bad = list(args); bad[20] = 3                      # chunks must divide the images per bias window (here 1)
+    assert lib.pswin_attn_bwd_ex(*bad) == ERR
+    # AdamW over the flat buffer: multiple of 4 elements, aligned, sane hyper-parameters, device step counter
+    ok = [p16, p16, p16, p16, None, 1024, 1e-4, 0.9, 0.999, 1e-8, 0.05, p16, None]
+    for i, v in ((5, 1022), (0, None), (11, None), (7, 1.0), (8, -0.1), (6, -1e-4), (0, p16 + 4)):
+        bad = list(ok); bad[i] = v
+        assert lib.pswin_adamw_flat(*bad) == ERR, (i, v)
+
+
 def test_product_never_imports_the_oracle():
     pkg = os.path.join(ROOT, "panoswintransformerobjectdetection_amd")
     for fn in os.listdir(pkg):
