@@ -312,6 +312,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert torch.isfinite(loss).item(), "non-finite loss"
+    # (outside the timed region) every parameter and every gradient of the last step is finite: a finite loss alone once let
+    # non-finite stem weight gradients through
+    assert all(bool(torch.isfinite(p).all()) for p in model.parameters()), "non-finite parameter after the timed steps"
+    assert bool(torch.isfinite(reducer.flat).all()), "non-finite gradient in the last step"
 
     if rank == 0:
         ms = elapsed / args.steps * 1e3

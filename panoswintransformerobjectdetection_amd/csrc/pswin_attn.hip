@@ -31,6 +31,7 @@
 //   * Q/K/V/dO fragments are loaded straight from HBM in MFMA operand layout (lane = row & 15, 8 contiguous
 //     head-dim elements per lane = one 16-byte load for bf16): no staging pass for the row-wise operands.
 #include <cstdlib>
+#include <type_traits>
 
 #include "pswin_attn_frag.hpp"
 
@@ -669,15 +670,19 @@ __global__ __launch_bounds__(128, 2) void attn_bwd_pair_kernel(AttnArgs a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) ds4[tt][tj][e] = p4[tt][tj][e] * (ds4[tt][tj][e] - delta[e]);
                     gsum[tt][tj] = gsum[tt][tj] + ds4[tt][tj];
-                    // dS^T[j][local i .. +3], local i = 16 tt + 4 g
-                    const bf16x4 b = {(__bf16)ds4[tt][tj][0], (__bf16)ds4[tt][tj][1], (__bf16)ds4[tt][tj][2], (__bf16)ds4[tt][tj][3]};
-                    *reinterpret_cast<bf16x4*>(timg + timg_off(16 * tj + c, 4 * tt + g)) = b;
                 }
             }
 #pragma unroll
             for (int tj = 0; tj < 4; ++tj) {
                 pf[tj] = pack_frag<DT>(p4[0][tj], p4[1][tj]);
                 dsf[tj] = pack_frag<DT>(ds4[0][tj], ds4[1][tj]);
+                // dS^T[j][local i .. +3], local i = 16 tt + 4 g: the two halves of the fragment just packed (one rounding, one
+                // conversion per value)
+                typedef __attribute__((ext_vector_type(2))) unsigned long long u64x2_t;
+                const u64x2_t halves = __builtin_bit_cast(u64x2_t, dsf[tj].v);
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt)
+                    *reinterpret_cast<unsigned long long*>(timg + timg_off(16 * tj + c, 4 * tt + g)) = halves[tt];
             }
         }
         PSWIN_STAMP(1);
@@ -685,12 +690,21 @@ __global__ __launch_bounds__(128, 2) void attn_bwd_pair_kernel(AttnArgs a) {
         if (r + 1 < a.reps_per_chunk) load_ops(r + 1, cur);
 
         // partial dV^T / dK^T over this wave's 32 queries: [dt][tj], rows d = 16 dt + 4 g + e, column key j = 16 tj + c.
-        // wave 0 keeps dV and sends dK, wave 1 keeps dK and sends dV
-        Frag<DT> dot[2], qt[2];
+        // wave 0 keeps dV (= dO^T P) and sends dK (= Q^T dS), wave 1 keeps dK and sends dV.  The role is applied to the OPERANDS
+        // (which LDS image the transposed fragments come from: a scalar select; which packed fragment multiplies them: 32
+        // register selects) instead of to the 64 result registers of both products.
+        const char* keep_img = w == 0 ? doimg : qimg;
+        const char* send_img = w == 0 ? qimg : doimg;
+        Frag<DT> ka[2], sa[2], kb[4], sb[4];
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-            dot[dt] = tr32<false>(doimg, 4 * g, 16 * dt, c);
-            qt[dt] = tr32<false>(qimg, 4 * g, 16 * dt, c);
+            ka[dt] = tr32<false>(keep_img, 4 * g, 16 * dt, c);
+            sa[dt] = tr32<false>(send_img, 4 * g, 16 * dt, c);
+        }
+#pragma unroll
+        for (int tj = 0; tj < 4; ++tj) {
+            kb[tj] = w == 0 ? pf[tj] : dsf[tj];
+            sb[tj] = w == 0 ? dsf[tj] : pf[tj];
         }
         f32x4 keep[2][4];
         {
@@ -700,10 +714,8 @@ __global__ __launch_bounds__(128, 2) void attn_bwd_pair_kernel(AttnArgs a) {
 #pragma unroll
                 for (int dt = 0; dt < 2; ++dt) {
                     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                    const f32x4 dvp = mma32<DT>(dot[dt], pf[tj], z);
-                    const f32x4 dkp = mma32<DT>(qt[dt], dsf[tj], z);
-                    keep[dt][tj] = w == 0 ? dvp : dkp;
-                    *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(exch) + exch_off(16 * tj + c, 4 * dt + g)) = w == 0 ? dkp : dvp;
+                    keep[dt][tj] = mma32<DT>(ka[dt], kb[tj], z);
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(exch) + exch_off(16 * tj + c, 4 * dt + g)) = mma32<DT>(sa[dt], sb[tj], z);
                 }
         }
         PSWIN_STAMP(2);

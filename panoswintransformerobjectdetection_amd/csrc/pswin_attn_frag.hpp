@@ -231,10 +231,7 @@ template <int DT>
 __device__ inline void store_row8_at(rsrc_t rs, unsigned row_boff, int g, f32x4 q0, f32x4 q1) {
     const int d0 = 8 * (g >> 1) + 16 * (g & 1);
     if constexpr (DT == PSWIN_BF16) {
-        unsigned a0 = (unsigned)f32_to_bf16_bits(q0[0]) | ((unsigned)f32_to_bf16_bits(q0[1]) << 16);
-        unsigned a1 = (unsigned)f32_to_bf16_bits(q0[2]) | ((unsigned)f32_to_bf16_bits(q0[3]) << 16);
-        unsigned b0 = (unsigned)f32_to_bf16_bits(q1[0]) | ((unsigned)f32_to_bf16_bits(q1[1]) << 16);
-        unsigned b1 = (unsigned)f32_to_bf16_bits(q1[2]) | ((unsigned)f32_to_bf16_bits(q1[3]) << 16);
+        unsigned a0 = pack2_bf16(q0[0], q0[1]), a1 = pack2_bf16(q0[2], q0[3]), b0 = pack2_bf16(q1[0], q1[1]), b1 = pack2_bf16(q1[2], q1[3]);
         swap16_u32(a0, b0);
         swap16_u32(a1, b1);
         const u32x4 v = {a0, a1, b0, b1};

@@ -47,7 +47,7 @@ __device__ inline void store_vec(void* base, size_t elem_off, const float (&v)[V
         u32x4 raw;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            raw[e] = (unsigned int)f32_to_bf16_bits(v[2 * e]) | ((unsigned int)f32_to_bf16_bits(v[2 * e + 1]) << 16);
+            raw[e] = pack2_bf16(v[2 * e], v[2 * e + 1]);
         *reinterpret_cast<u32x4*>(reinterpret_cast<unsigned short*>(base) + elem_off) = raw;
     } else {
         f32x4 r = {v[0], v[1], v[2], v[3]};

@@ -36,6 +36,13 @@ __device__ inline unsigned short f32_to_bf16_bits(float f) {
     __bf16 b = (__bf16)f;
     return __builtin_bit_cast(unsigned short, b);
 }
+// two f32 -> one dword of two bf16 (lo in bits 0-15) with ONE v_cvt_pk_bf16_f32: `f32_to_bf16_bits(lo) | f32_to_bf16_bits(hi) << 16`
+// compiles to two conversions, a shift and an or (seen in the ISA of every kernel that packed its outputs that way)
+typedef __attribute__((ext_vector_type(2))) float pswin_f32x2_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 pswin_bf16x2_t;
+__device__ inline unsigned int pack2_bf16(float lo, float hi) {
+    return __builtin_bit_cast(unsigned int, __builtin_convertvector(pswin_f32x2_t{lo, hi}, pswin_bf16x2_t));
+}
 
 // 4 consecutive elements of a row, as f32, from an f32 or bf16 buffer
 template <int DT>
@@ -59,8 +66,8 @@ __device__ inline void store4(void* base, size_t elem_off, f32x4 v) {
         *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(base) + elem_off) = v;
     } else {
         u32x2 raw;
-        raw[0] = (unsigned int)f32_to_bf16_bits(v[0]) | ((unsigned int)f32_to_bf16_bits(v[1]) << 16);
-        raw[1] = (unsigned int)f32_to_bf16_bits(v[2]) | ((unsigned int)f32_to_bf16_bits(v[3]) << 16);
+        raw[0] = pack2_bf16(v[0], v[1]);
+        raw[1] = pack2_bf16(v[2], v[3]);
         *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(base) + elem_off) = raw;
     }
 }

@@ -27,7 +27,7 @@ __device__ inline void swap16_u32(unsigned& a, unsigned& b) {
     b = r[1];
 }
 __device__ inline unsigned pack_bf16(float lo, float hi) {
-    return (unsigned)f32_to_bf16_bits(lo) | ((unsigned)f32_to_bf16_bits(hi) << 16);
+    return pack2_bf16(lo, hi);
 }
 // lane (c, g) holds quads q0 = col[4g..4g+3], q1 = col[16+4g..16+4g+3] of a 32-column group of one row -> after the
 // exchange 8 consecutive columns starting at 8 (g >> 1) + 16 (g & 1)

@@ -100,10 +100,10 @@ __global__ __launch_bounds__(256) void window_gather8_kernel(const float* __rest
         const float m = src[u] >= 0 ? sc : 0.f;                                                            // padding slots are zero rows
         const f32x4 av = (SCALE || src[u] < 0) ? a[u] * m : a[u], cv = (SCALE || src[u] < 0) ? c[u] * m : c[u];
         u32x4 o;
-        o[0] = (unsigned)f32_to_bf16_bits(av[0]) | ((unsigned)f32_to_bf16_bits(av[1]) << 16);
-        o[1] = (unsigned)f32_to_bf16_bits(av[2]) | ((unsigned)f32_to_bf16_bits(av[3]) << 16);
-        o[2] = (unsigned)f32_to_bf16_bits(cv[0]) | ((unsigned)f32_to_bf16_bits(cv[1]) << 16);
-        o[3] = (unsigned)f32_to_bf16_bits(cv[2]) | ((unsigned)f32_to_bf16_bits(cv[3]) << 16);
+        o[0] = pack2_bf16(av[0], av[1]);
+        o[1] = pack2_bf16(av[2], av[3]);
+        o[2] = pack2_bf16(cv[0], cv[1]);
+        o[3] = pack2_bf16(cv[2], cv[3]);
         if (src[u] < 0) o = u32x4{0u, 0u, 0u, 0u};                                                       // exact zeros (x may hold inf / nan)
         if (r[u] < (unsigned)n_slots) *reinterpret_cast<u32x4*>(win + ((size_t)b * n_slots + r[u]) * C + 8 * (size_t)lane) = o;
     }

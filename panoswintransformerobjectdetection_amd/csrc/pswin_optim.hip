@@ -43,8 +43,7 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* __restrict__ p, 
         reinterpret_cast<f32x4*>(m)[i] = mv;
         reinterpret_cast<f32x4*>(v)[i] = vv;
         if (lowp) {
-            u32x2 o = {(unsigned)f32_to_bf16_bits(pv[0]) | ((unsigned)f32_to_bf16_bits(pv[1]) << 16),
-                       (unsigned)f32_to_bf16_bits(pv[2]) | ((unsigned)f32_to_bf16_bits(pv[3]) << 16)};
+            u32x2 o = {pack2_bf16(pv[0], pv[1]), pack2_bf16(pv[2], pv[3])};
             reinterpret_cast<u32x2*>(lowp)[i] = o;
         }
     }

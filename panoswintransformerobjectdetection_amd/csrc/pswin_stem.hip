@@ -71,6 +71,9 @@ __device__ inline void swap16_u32(unsigned& a, unsigned& b) {
     b = r[1];
 }
 
+// NOT pack2_bf16 (one v_cvt_pk_bf16_f32 for both values) in this file: with it the stem's weight gradients came out non-finite
+// (tests/test_backbone_gpu.py::test_hipgraph_replay_matches_eager, 256x512 input) -- the operands here often come straight from
+// MFMA accumulators, and the two-source form evidently does not get the wait states the one-value form gets (see the note above).
 __device__ inline unsigned pack_bf16(float lo, float hi) {
     return (unsigned)f32_to_bf16_bits(lo) | ((unsigned)f32_to_bf16_bits(hi) << 16);
 }
