@@ -136,6 +136,7 @@ def main():
     ap.add_argument("--eager", action="store_true", help="do not capture the step into a HIP graph")
     ap.add_argument("--model", default="T", choices=["T", "S"], help="PanoSwin-T (depths 2-2-6-2, the headline) or -S (2-2-18-2)")
     ap.add_argument("--height", type=int, default=512, help="panorama height; width = 2 * height (headline: 512)")
+    ap.add_argument("--graph-heads", type=int, default=1, help="--config maskrcnn: capture the head stand-ins into a hipGraph too (1) or run them eagerly (0)")
     ap.add_argument("--torch-adamw", action="store_true", help="torch.optim.AdamW(fused=True) instead of the one-launch HIP update (A/B)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); 'gloo' lets two "
                     "ranks rehearse the N > 1 code path on one GPU together with --device")
@@ -439,6 +440,11 @@ def main_maskrcnn(args):
     torch.cuda.set_stream(cap_stream)
     _lib.load()
     batch = 2 if args.batch == 8 else args.batch          # configs[3]: batch = 2 per GPU
+    if os.environ.get("PSWIN_MIOPEN_FIND") == "1":
+        # one-off: let MIOpen search its solvers for the head stand-ins' convolutions and record the results in
+        # MIOPEN_USER_DB_PATH (tools/miopen_find_heads.sh copies them into the shipped find-db); without a record MIOpen's
+        # immediate mode runs these shapes on its naive reference kernels
+        torch.backends.cudnn.benchmark = True
     H = args.height
     torch.manual_seed(0)
     model = MiniMaskRCNN(dict(TCFG, compute_dtype=torch.bfloat16)).to(dev).train()
@@ -472,8 +478,26 @@ def main_maskrcnn(args):
         red.pack_grads()
         return gbuf[0]
 
-    seq = GraphedSequence([phase_fwd, phase_bwd], warmup=2, stream=cap_stream)
+    def phase_heads():
+        feats = [o.detach().requires_grad_(True) for o in state["outs"]]
+        for p in head_params:
+            p.grad = None
+        losses = model.heads_loss(feats, targets, (H, 2 * H))
+        total = sum(losses.values())
+        total.backward()
+        for g, f in zip(gbuf, feats):
+            g.copy_(f.grad)
+        state["losses"] = losses
+        return total
+
+    # --graph-heads: the head stand-ins (static shapes, no host synchronisation) captured as a third hipGraph between the two
+    # backbone graphs instead of ~2,000 eager launches
+    graph_heads = bool(args.graph_heads)
+    seq = GraphedSequence([phase_fwd, phase_heads, phase_bwd] if graph_heads else [phase_fwd, phase_bwd], warmup=2, stream=cap_stream)
     g_opt = GraphedCallable(opt_bb.step, warmup=1, stream=seq.stream)
+    if graph_heads:
+        opt_hd = torch.optim.AdamW(head_params, lr=1e-4, weight_decay=0.05, fused=True, capturable=True)
+        g_opt_hd = GraphedCallable(opt_hd.step, warmup=1, stream=seq.stream)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
     parts = []
 
@@ -483,16 +507,20 @@ def main_maskrcnn(args):
         outs = seq.calls[0]()
         if record:
             ev[1].record()
-        feats = [o.detach().requires_grad_(True) for o in outs]
-        opt_hd.zero_grad(set_to_none=True)
-        losses = model.heads_loss(feats, targets, (H, 2 * H))
-        total = sum(losses.values())
-        total.backward()
-        for g, f in zip(gbuf, feats):
-            g.copy_(f.grad)
+        if graph_heads:
+            total = seq.calls[1]()
+            losses = state["losses"]
+        else:
+            feats = [o.detach().requires_grad_(True) for o in outs]
+            opt_hd.zero_grad(set_to_none=True)
+            losses = model.heads_loss(feats, targets, (H, 2 * H))
+            total = sum(losses.values())
+            total.backward()
+            for g, f in zip(gbuf, feats):
+                g.copy_(f.grad)
         if record:
             ev[2].record()
-        seq.calls[1]()
+        seq.calls[-1]()
         if record:
             ev[3].record()
         if world > 1:
@@ -506,7 +534,10 @@ def main_maskrcnn(args):
                 at += p.numel()
         red.finish()
         g_opt()
-        opt_hd.step()
+        if graph_heads:
+            g_opt_hd()
+        else:
+            opt_hd.step()
         if record:
             ev[4].record()
             torch.cuda.synchronize()
@@ -544,7 +575,7 @@ def main_maskrcnn(args):
                                    f"PyTorch stand-ins, parity unpinned), synthetic COCO-shaped targets, 3x{H}x{2 * H}, fwd + bwd + AdamW",
                        "batch_per_gpu": batch, "global_batch": batch * world, "parallelism": f"dp{world}",
                        "device": torch.cuda.get_device_name(dev)},
-            "step_breakdown_ms": {"backbone_forward_graph": round(br[0], 3), "heads_forward_backward_eager": round(br[1], 3),
+            "step_breakdown_ms": {"backbone_forward_graph": round(br[0], 3), "heads_forward_backward": round(br[1], 3), "heads_in_hipgraph": graph_heads,
                                   "backbone_backward_graph": round(br[2], 3), "allreduce_and_optimizers": round(br[3], 3)},
             "losses": {k: round(float(v), 4) for k, v in losses.items()},
         }

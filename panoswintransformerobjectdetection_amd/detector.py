@@ -39,6 +39,17 @@ def box_iou(a, b):
     return inter / (area_a[:, None] + area_b[None] - inter).clamp(min=1e-6)
 
 
+_CONSTS = {}
+
+
+def _const(values, like):
+    """A small constant tensor on `like`'s device, built once (a host-to-device copy per call would also break hipGraph capture)."""
+    key = (tuple(float(v) for v in values), str(like.device), like.dtype)
+    if key not in _CONSTS:
+        _CONSTS[key] = torch.tensor(key[0], device=like.device, dtype=like.dtype)
+    return _CONSTS[key]
+
+
 def encode_deltas(src, dst, stds):
     """DeltaXYWHBBoxCoder.encode (means 0)"""
     sw, sh = (src[:, 2] - src[:, 0]).clamp(min=1e-3), (src[:, 3] - src[:, 1]).clamp(min=1e-3)
@@ -46,11 +57,11 @@ def encode_deltas(src, dst, stds):
     sx, sy = (src[:, 0] + src[:, 2]) * 0.5, (src[:, 1] + src[:, 3]) * 0.5
     dx, dy = (dst[:, 0] + dst[:, 2]) * 0.5, (dst[:, 1] + dst[:, 3]) * 0.5
     d = torch.stack([(dx - sx) / sw, (dy - sy) / sh, torch.log(dw / sw), torch.log(dh / sh)], 1)
-    return d / d.new_tensor(stds)
+    return d / _const(stds, d)
 
 
 def decode_deltas(src, deltas, stds, max_shape):
-    d = deltas * deltas.new_tensor(stds)
+    d = deltas * _const(stds, deltas)
     sw, sh = src[:, 2] - src[:, 0], src[:, 3] - src[:, 1]
     sx, sy = (src[:, 0] + src[:, 2]) * 0.5, (src[:, 1] + src[:, 3]) * 0.5
     clip = abs(math.log(16 / 1000))
@@ -106,8 +117,15 @@ class RPNHead(nn.Module):
         return outs
 
 
+_ANCHORS = {}
+
+
 def make_anchors(shapes, strides, device, scale=8.0, ratios=(0.5, 1.0, 2.0)):
-    """AnchorGenerator(scales=[8], ratios=[0.5, 1, 2]): per level [H * W * 3, 4], location-major (the conv output order)."""
+    """AnchorGenerator(scales=[8], ratios=[0.5, 1, 2]): per level [H * W * 3, 4], location-major (the conv output order).
+    Cached per geometry: constants of the step (and building them copies host data, which a hipGraph capture refuses)."""
+    key = (tuple(tuple(int(v) for v in sh) for sh in shapes), tuple(strides), str(device), scale, tuple(ratios))
+    if key in _ANCHORS:
+        return _ANCHORS[key]
     out = []
     for (H, W), s in zip(shapes, strides):
         r = torch.tensor(ratios, device=device)
@@ -117,6 +135,7 @@ def make_anchors(shapes, strides, device, scale=8.0, ratios=(0.5, 1.0, 2.0)):
         sy, sx = torch.meshgrid(torch.arange(H, device=device) * s, torch.arange(W, device=device) * s, indexing="ij")
         shift = torch.stack([sx, sy, sx, sy], -1).reshape(-1, 1, 4).float()
         out.append((shift + base[None]).reshape(-1, 4))
+    _ANCHORS[key] = out
     return out
 
 
@@ -159,11 +178,20 @@ def roi_align(feats, strides, rois, out_size, finest_scale=56, samples=2):
         x1, y1, x2, y2 = [rois[..., i] / s for i in range(4)]
         gx = (x1[..., None] + (x2 - x1).clamp(min=1.0)[..., None] * t) / W * 2 - 1                # [B, n, S]
         gy = (y1[..., None] + (y2 - y1).clamp(min=1.0)[..., None] * t) / H * 2 - 1
+        # Border replication for the RoIs of this level (clamping the sample centres half a pixel inside the map is the same thing),
+        # and the RoIs of OTHER levels pushed outside the map with zero padding: they then read zeros and, in the backward pass,
+        # scatter nothing -- sampled on every level and masked afterwards, four fifths of grid_sample's atomic adds carried zeros
+        gx = gx.clamp(-1 + 1.0 / W, 1 - 1.0 / W)
+        gy = gy.clamp(-1 + 1.0 / H, 1 - 1.0 / H)
+        sel = (lvl == l)[..., None]
+        gx = torch.where(sel, gx, gx.new_full((), 3.0))
+        gy = torch.where(sel, gy, gy.new_full((), 3.0))
         grid = torch.stack([gx[:, :, None, :].expand(B, n, S, S), gy[:, :, :, None].expand(B, n, S, S)], -1).reshape(B, n * S, S, 2)
-        smp = F.grid_sample(f, grid.to(f.dtype), mode="bilinear", padding_mode="border", align_corners=False)   # [B, C, n*S, S]
+        # sampled in fp32: the backward pass of grid_sample scatters with atomic adds, which are native for f32 and a
+        # compare-and-swap loop for bf16 (16.6 ms per launch, ~100 ms of a 133 ms head step on MI355X)
+        smp = F.grid_sample(f.float(), grid.float(), mode="bilinear", padding_mode="zeros", align_corners=False).to(f.dtype)   # [B, C, n*S, S]
         smp = F.avg_pool2d(smp.view(B, C, n, S, S).permute(0, 2, 1, 3, 4).reshape(B * n, C, S, S), samples)
-        w = (lvl == l).reshape(B * n, 1, 1, 1).to(smp.dtype)
-        out = smp * w if out is None else out + smp * w
+        out = smp if out is None else out + smp
     return out
 
 
