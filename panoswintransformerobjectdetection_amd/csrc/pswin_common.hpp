@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "pswin.h"
 
 #define PSWIN_CHECK_ARG(cond) \
@@ -106,6 +108,22 @@ __global__ static void colsum_kernel(const float* __restrict__ part, int R, int 
 
 inline void launch_colsum(const float* part, int R, int N, float* out, hipStream_t st) {
     hipLaunchKernelGGL(colsum_kernel, dim3((N + 15) / 16), dim3(1024), 0, st, part, R, N, out);
+}
+
+// Opt a kernel in to `bytes` of dynamic LDS (> 64 KB needs hipFuncAttributeMaxDynamicSharedMemorySize) on the CURRENT device.
+// The attribute is per device, so the "already done" memo is a bit per device ordinal (lock-free; setting it twice is harmless);
+// a failure is returned to the caller instead of surfacing later as an unexplained launch error.
+inline int ensure_dynamic_lds(const void* kernel, size_t bytes, std::atomic<unsigned long long>& done) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return (int)e;
+    const bool memo = dev >= 0 && dev < 64;
+    const unsigned long long bit = memo ? 1ull << dev : 0ull;
+    if (memo && (done.load(std::memory_order_acquire) & bit)) return PSWIN_OK;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return (int)e;
+    if (memo) done.fetch_or(bit, std::memory_order_release);
+    return PSWIN_OK;
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }

@@ -374,12 +374,8 @@ constexpr size_t fused_lds(bool) { return WQ_BYTES + WP_BYTES + BQ_BYTES + TAB_B
 
 template <bool SAVE>
 int launch_fused(const FusedArgs& a, hipStream_t st) {
-    static bool configured = false;
-    if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&win_fused_fwd_kernel<SAVE>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)fused_lds(SAVE));
-        configured = true;
-    }
+    static std::atomic<unsigned long long> configured{0};
+    if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&win_fused_fwd_kernel<SAVE>), fused_lds(SAVE), configured)) return rc;
     int grid = a.nb < 256 ? a.nb : 256;              // one persistent workgroup per CU
     hipLaunchKernelGGL((win_fused_fwd_kernel<SAVE>), dim3(grid), dim3(FTHREADS), fused_lds(SAVE), st, a);
     PSWIN_LAUNCH_RET();

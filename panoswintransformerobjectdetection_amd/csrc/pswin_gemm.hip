@@ -242,12 +242,8 @@ int launch(const void* x, const void* w, const float* bias, void* y, int M, int 
            hipStream_t st, int* grid_out = nullptr) {
     constexpr int K = 32 * KS, N = 16 * NT;
     constexpr size_t lds = (size_t)N * (K == 96 ? 192 : 2 * K + 16) + N * sizeof(float) * (EPI == 2 ? 5 : 1);
-    static bool configured = false;
-    if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&skinny_gemm_kernel<KS, NT, RT, EPI>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        configured = true;
-    }
+    static std::atomic<unsigned long long> configured{0};
+    if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&skinny_gemm_kernel<KS, NT, RT, EPI>), lds, configured)) return rc;
     const int ntiles = (M + 16 * RT - 1) / (16 * RT);
     int grid = (ntiles + 3) / 4;
     if (grid > MAX_GRID) grid = MAX_GRID;

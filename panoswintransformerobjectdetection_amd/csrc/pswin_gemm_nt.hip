@@ -302,11 +302,8 @@ template <int BM, int EPI>
 int launch_nt(const void* x, const void* w, const float* bias, void* y, int M, int N, int K, hipStream_t st, const void* aux = nullptr,
               float* partial = nullptr) {
     constexpr size_t lds = 2 * (size_t)(BM + BN) * BK * 2;
-    static bool configured = false;
-    if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        configured = true;
-    }
+    static std::atomic<unsigned long long> configured{0};
+    if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, EPI>), lds, configured)) return rc;
     const int tiles_m = (M + BM - 1) / BM, tiles_n = N / BN;
     hipLaunchKernelGGL((gemm_nt_kernel<BM, EPI>), dim3(tiles_m * tiles_n), dim3(NT_THREADS), lds, st,
                        reinterpret_cast<const unsigned short*>(x), reinterpret_cast<const unsigned short*>(w), bias,

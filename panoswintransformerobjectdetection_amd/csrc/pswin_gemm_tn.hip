@@ -152,11 +152,8 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(const unsigned s
 template <int PA, int PB>
 int launch_tn(const void* dy, const void* x, float* partial, int M, int N, int K, int splits, hipStream_t st) {
     constexpr size_t lds = 2 * (size_t)(PA + PB) * PANEL;
-    static bool configured = false;
-    if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_kernel<PA, PB>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        configured = true;
-    }
+    static std::atomic<unsigned long long> configured{0};
+    if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&gemm_tn_kernel<PA, PB>), lds, configured)) return rc;
     const int tiles_k = K / (64 * PA), tiles_n = N / (64 * PB);
     const int rows_per_split = ((M + splits - 1) / splits + MSTEP - 1) / MSTEP * MSTEP;
     hipLaunchKernelGGL((gemm_tn_kernel<PA, PB>), dim3(tiles_k * tiles_n * splits), dim3(TN_THREADS), lds, st,

@@ -74,8 +74,15 @@ __device__ inline void swap16_u32(unsigned& a, unsigned& b) {
 // NOT pack2_bf16 (one v_cvt_pk_bf16_f32 for both values) in this file: with it the stem's weight gradients came out non-finite
 // (tests/test_backbone_gpu.py::test_hipgraph_replay_matches_eager, 256x512 input) -- the operands here often come straight from
 // MFMA accumulators, and the two-source form evidently does not get the wait states the one-value form gets (see the note above).
+#ifndef PSWIN_STEM_PACK2
+#define PSWIN_STEM_PACK2 0
+#endif
 __device__ inline unsigned pack_bf16(float lo, float hi) {
+#if PSWIN_STEM_PACK2
+    return pack2_bf16(lo, hi);
+#else
     return (unsigned)f32_to_bf16_bits(lo) | ((unsigned)f32_to_bf16_bits(hi) << 16);
+#endif
 }
 __device__ inline float bf_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
 __device__ inline float bf_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
