@@ -200,3 +200,32 @@ if __name__ == "__main__":
         with torch.no_grad():
             outs = m(torch.randn(1, 3, 128, 256))
         print([tuple(o.shape) for o in outs])
+
+
+def load_reference_checkpoint_module():
+    """The reference's checkpoint loader, ``mmcv_custom/checkpoint.py``, imported in place with stand-ins for the third-party
+    modules its import block names (torchvision, mmcv.fileio / parallel / utils / runner: none of them is reached when a local
+    file is loaded on one process).  Dev container only; returns None when /root/reference is absent."""
+    if "ckpt" in _CACHE:
+        return _CACHE["ckpt"]
+    path = os.path.join(REFERENCE_ROOT, "mmcv_custom", "checkpoint.py")
+    if not os.path.isfile(path):
+        _CACHE["ckpt"] = None
+        return None
+    saved = {k: sys.modules.get(k) for k in ("torchvision", "mmcv", "mmcv.fileio", "mmcv.parallel", "mmcv.utils", "mmcv.runner")}
+    try:
+        _mk("torchvision")
+        mmcv = _mk("mmcv")
+        mmcv.fileio = _mk("mmcv.fileio", FileClient=object, load=lambda *a, **k: None)
+        mmcv.parallel = _mk("mmcv.parallel", is_module_wrapper=lambda m: False)
+        mmcv.utils = _mk("mmcv.utils", mkdir_or_exist=lambda *a, **k: None, Registry=_Registry)
+        mmcv.runner = _mk("mmcv.runner", get_dist_info=lambda: (0, 1))
+        mod = _load_file_module("ref_mmcv_custom_checkpoint", path)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    _CACHE["ckpt"] = mod
+    return mod

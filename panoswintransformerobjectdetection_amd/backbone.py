@@ -486,8 +486,15 @@ class SimplePanoSwinTransformer(nn.Module, DoubleModeModule):
         (instead of ~100 small cast kernels); plain attributes, never part of the state dict."""
         fp = self.__dict__.get("_flat_pair")
         if fp is not None and fp[1].dtype == cd:
-            if not self.__dict__.get("_lowp_external"):     # (optim.FlatAdamW writes the copy with the update itself)
+            # optim.FlatAdamW writes the low-precision copy with the update itself; the copy is then skipped here -- but only while
+            # nothing else has touched the weights since (load_state_dict, init_weights, another optimizer, ...): see
+            # _weights_signature.  The optimizer is held weakly: once it is gone every forward pass copies again.
+            ext = self.__dict__.get("_lowp_external")
+            if ext is not None and ext() is None:
+                ext = self.__dict__["_lowp_external"] = None
+            if ext is None or self.__dict__.get("_lowp_sig") != self._weights_signature():
                 fp[1].copy_(fp[0])                  # every master weight -> its low-precision view, one kernel
+                self.__dict__["_lowp_sig"] = self._weights_signature()
             if for_backward:
                 self._refresh_transposed(cd)
             return
@@ -506,6 +513,19 @@ class SimplePanoSwinTransformer(nn.Module, DoubleModeModule):
         torch._foreach_copy_(dst, src)
         if for_backward:
             self._refresh_transposed(cd)
+
+    def _weights_signature(self):
+        """Changes when a master weight is written through PyTorch: the version counters of the flat buffer (an optimizer on the
+        flat parameter) and of every parameter (load_state_dict, nn.init, ``p.copy_``).  optim.FlatAdamW's kernel writes through raw
+        pointers and bumps neither -- which is the point: after its step the shadow is already fresh.  Writes through ``p.data`` are
+        invisible to autograd's counters; such callers (dp.GradReducer.broadcast_parameters does) call mark_weights_changed()."""
+        fp = self.__dict__["_flat_pair"]
+        return (fp[0]._version, sum(p._version for p in self.parameters()), self.__dict__.get("_lowp_epoch", 0))
+
+    def mark_weights_changed(self):
+        """Tell the model that its weights were modified behind autograd's back (``p.data`` writes, raw pointers): the next forward
+        pass refreshes the low-precision shadows whatever optimizer is attached."""
+        self.__dict__["_lowp_epoch"] = self.__dict__.get("_lowp_epoch", 0) + 1
 
     @torch.no_grad()
     def _refresh_transposed(self, cd):

@@ -227,6 +227,8 @@ class GradReducer:
             return
         for p in module.parameters():
             dist.broadcast(p.data, src=src, group=self.group)
+        if hasattr(module, "mark_weights_changed"):          # p.data writes are invisible to the version counters
+            module.mark_weights_changed()
 
 
 # -- backward in two pieces (all-reduce overlapped with the second piece) ------------------------------------------

@@ -28,13 +28,16 @@ class FlatAdamW(torch.optim.Optimizer):
         self.state[flat_param] = dict(step=torch.zeros((), dtype=torch.float32, device=flat_param.device),      # steps taken so far
                                       exp_avg=torch.zeros_like(flat_param.data), exp_avg_sq=torch.zeros_like(flat_param.data))
         self.lowp = None
+        self._model = None
         pair = None if model is None else model.__dict__.get("_flat_pair")
         if pair is not None:
             if pair[0].data_ptr() != flat_param.data_ptr() or pair[1].dtype != torch.bfloat16:
                 raise PswinError("FlatAdamW: the model's flat shadow does not belong to this flat parameter")
+            import weakref
             self.lowp = pair[1]
-            self.lowp.copy_(flat_param.data)             # in step with the weights before the first forward pass
-            model.__dict__["_lowp_external"] = True      # backbone._refresh_lowp: the shadow is kept fresh here
+            self._model = weakref.ref(model)
+            model.__dict__["_lowp_external"] = weakref.ref(self)      # backbone._refresh_lowp: the shadow is kept fresh here ...
+            self.sync_lowp()                                          # ... starting in step with the weights as they are now
 
     exp_avg = property(lambda self: self.state[self.flat]["exp_avg"])
     exp_avg_sq = property(lambda self: self.state[self.flat]["exp_avg_sq"])
@@ -42,9 +45,15 @@ class FlatAdamW(torch.optim.Optimizer):
 
     @torch.no_grad()
     def sync_lowp(self):
-        """After the weights were changed by anything but step() (checkpoint load, broadcast)."""
+        """Refresh the bf16 shadow from the master weights now.  Needed by hand only where the model cannot notice a change by
+        itself: weights edited between REPLAYS of a captured step (no Python runs there), or through raw pointers / ``p.data``
+        without model.mark_weights_changed().  Everything PyTorch tracks (load_state_dict, nn.init, another optimizer's step) is
+        detected by the next forward pass (backbone._weights_signature)."""
         if self.lowp is not None:
             self.lowp.copy_(self.flat.data)
+            m = self._model() if getattr(self, "_model", None) is not None else None
+            if m is not None:
+                m.__dict__["_lowp_sig"] = m._weights_signature()
 
     @torch.no_grad()
     def step(self, closure=None):
