@@ -319,6 +319,17 @@ int pswin_transpose_jobs(const pswin_transpose_job* jobs, int n_jobs, void* stre
  * taken.  Same arithmetic, element by element, as torch.optim.AdamW. */
 int pswin_adamw_flat(float* p, const float* g, float* m, float* v, void* p_bf16, long long n, double lr, double beta1, double beta2, double eps,
                      double weight_decay, const float* step, void* stream);
+/* The same update with PARAMETER GROUPS, as the reference's optimizer is configured
+ * (configs/swin/mask_rcnn_swin_tiny_patch4_window7_mstrain_480-800_adamw_1x_coco.py:64-67: paramwise_cfg.custom_keys give every parameter
+ * whose name contains 'norm' / 'relative_position_bias_table' / 'absolute_pos_embed' decay_mult = 0; mmcv's optimizer constructor turns that
+ * into per-parameter groups).  group_of: DEVICE array of n / 4 bytes, the group (< n_groups <= PSWIN_ADAMW_MAX_GROUPS) of elements
+ * 4 i .. 4 i + 3 (parameters start on 64-element boundaries of the flat buffer, so a granule never straddles two); lr_mult / decay_mult:
+ * HOST arrays of n_groups multipliers (copied into the kernel arguments).  Group k is updated exactly as torch.optim.AdamW updates a
+ * group with lr * lr_mult[k] and weight_decay * decay_mult[k].  group_of == NULL (n_groups 0): one group, = pswin_adamw_flat. */
+#define PSWIN_ADAMW_MAX_GROUPS 8
+int pswin_adamw_flat_groups(float* p, const float* g, float* m, float* v, void* p_bf16, long long n, const unsigned char* group_of,
+                            int n_groups, const float* lr_mult, const float* decay_mult, double lr, double beta1, double beta2, double eps,
+                            double weight_decay, const float* step, void* stream);
 int pswin_gemm_nt_supported(long long M, int K, int N);
 int pswin_gemm_nt(const void* x, const void* w, const float* bias, void* y, long long M, int K, int N, int tile_m, void* stream);
 /* The data gradient of the Mlp's fc2 fused with the backward of fc1's bias + nn.GELU (HOT:50-58):

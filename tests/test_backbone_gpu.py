@@ -446,3 +446,53 @@ def test_benched_workload_is_bitwise_reproducible():
     diff = [k for k in g1 if not torch.equal(g1[k], g2[k])]
     assert not diff, diff[:8]
     assert all(bool(torch.isfinite(v).all()) for v in g1.values())
+
+
+@pytest.mark.gpu
+def test_weights_changed_behind_the_flat_optimizer_reach_the_bf16_kernels():
+    """once optim.FlatAdamW keeps the bf16 weight shadow fresh, the forward pass stops re-casting it -- so a weight change
+    that does NOT go through its step() (load_state_dict after the optimizer is built, init_weights, a p.data write announced with
+    mark_weights_changed(), the optimizer being dropped) must be noticed by the next forward pass."""
+    import gc
+    from panoswintransformerobjectdetection_amd import SimplePanoSwinTransformer
+    from panoswintransformerobjectdetection_amd.dp import GradReducer
+    from panoswintransformerobjectdetection_amd.optim import FlatAdamW
+    cfg = dict(embed_dim=96, depths=[2, 2, 2, 2], num_heads=[3, 6, 12, 24], window_size=7, ape=True, drop_path_rate=0.0, pano_mode=True)
+    x = torch.randn(2, 3, 128, 256, device="cuda", generator=torch.Generator("cuda").manual_seed(3))
+
+    def fresh(seed):
+        torch.manual_seed(seed)
+        m = SimplePanoSwinTransformer(**cfg, compute_dtype=torch.bfloat16)
+        m.init_weights(None)
+        return m.cuda().eval()
+
+    def fwd(m):
+        with torch.no_grad():
+            return [o.clone() for o in m(x)]
+
+    other = fresh(1)
+    want = fwd(other)
+    m = fresh(0)
+    red = GradReducer(m, pack=True)
+    flat = red.flatten_parameters(m, torch.bfloat16)
+    opt = FlatAdamW(flat, lr=1e-3, model=m)
+    before = fwd(m)
+    assert not torch.equal(before[0], want[0])
+    m.load_state_dict(other.state_dict())                      # (1) tracked by the parameters' version counters
+    for a, b in zip(fwd(m), want):
+        assert torch.equal(a, b)
+    with torch.no_grad():                                      # (2) a raw write + the explicit notice
+        for p, q in zip(m.parameters(), fresh(0).parameters()):
+            p.data.copy_(q.data)
+    m.mark_weights_changed()
+    for a, b in zip(fwd(m), before):
+        assert torch.equal(a, b)
+    m.load_state_dict(other.state_dict())
+    fwd(m)
+    del opt                                                    # (3) optimizer gone: every forward pass refreshes again
+    gc.collect()
+    with torch.no_grad():
+        for p, q in zip(m.parameters(), fresh(0).parameters()):
+            p.data.copy_(q.data)
+    for a, b in zip(fwd(m), before):
+        assert torch.equal(a, b)

@@ -96,3 +96,19 @@ def test_strict_raises_with_the_reference_wording(tmp_path):
         p = tmp_path / "bad.pth"
         torch.save([1, 2, 3], p)
         load_checkpoint(m, str(p))
+
+
+def test_paramwise_groups_follow_the_mmcv_rule():
+    """custom_keys of the reference configs (configs/swin/mask_rcnn_swin_tiny_..._1x_coco.py:64-67): substring match on the full name,
+    longest key first."""
+    from panoswintransformerobjectdetection_amd.optim import REFERENCE_PARAMWISE_CFG, paramwise_groups
+    m = SimplePanoSwinTransformer(**TINY, pano_mode=True)
+    named = list(m.named_parameters())
+    got = {n: (a, b) for n, a, b in paramwise_groups(named, REFERENCE_PARAMWISE_CFG, "backbone")}
+    for n, _ in named:
+        assert got[n] == ((1.0, 0.0) if "norm" in n else (1.0, 1.0)), n
+    assert got["patch_embed.norm.weight"] == (1.0, 0.0) and got["patch_embed.proj.1.weight"] == (1.0, 1.0)     # BatchNorm has no 'norm' in its name
+    assert got["layers.0.blocks.0.attn.sphere_position_beta_table_Te"] == (1.0, 1.0)                            # no key of the config matches the tables
+    pw = dict(custom_keys={"norm": dict(decay_mult=0.), "layers.0.blocks.0.norm1": dict(lr_mult=2.0)})
+    got = {n: (a, b) for n, a, b in paramwise_groups(named, pw)}
+    assert got["layers.0.blocks.0.norm1.weight"] == (2.0, 1.0) and got["layers.0.blocks.1.norm1.weight"] == (1.0, 0.0)

@@ -939,3 +939,46 @@ def test_flat_adamw_state_dict_round_trip_with_torch_adamw(ops):
         oa2.step(); ob2.step()
     assert float(oa2.step_t) == 4.0
     assert torch.allclose(a.data, b.data, rtol=2e-6, atol=2e-7), (a.data - b.data).abs().max()
+
+
+def test_flat_adamw_parameter_groups_match_torch_adamw_groups(ops):
+    """optim.FlatAdamW(paramwise_cfg = the reference configs' custom_keys: decay_mult = 0 for 'norm' parameters,
+    configs/swin/mask_rcnn_swin_tiny_..._1x_coco.py:64-67) -- still ONE launch over the flat buffer, the groups in a byte map --
+    against torch.optim.AdamW with the per-parameter groups mmcv's optimizer constructor would build, 4 steps on the same
+    gradients: every parameter to f32 rounding; plus an lr_mult group to cover the second multiplier."""
+    from panoswintransformerobjectdetection_amd import SimplePanoSwinTransformer
+    from panoswintransformerobjectdetection_amd.dp import GradReducer
+    from panoswintransformerobjectdetection_amd.optim import REFERENCE_PARAMWISE_CFG, FlatAdamW, paramwise_groups
+    cfg = dict(embed_dim=32, depths=[2, 2, 2, 2], num_heads=[1, 2, 4, 8], ape=True, drop_path_rate=0.0)
+    pw = dict(custom_keys=dict(REFERENCE_PARAMWISE_CFG["custom_keys"], **{"abs_encoder": dict(lr_mult=0.1, decay_mult=0.5)}))
+    torch.manual_seed(5)
+    m = SimplePanoSwinTransformer(**cfg, compute_dtype=torch.bfloat16)
+    m.init_weights(None)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.add_(torch.randn_like(p) * 0.5)                 # norm gains / biases away from their 1 / 0 initial values
+    m = m.to(DEV)
+    named = list(m.named_parameters())
+    ref_params = {k: torch.nn.Parameter(p.detach().clone()) for k, p in named}
+    groups = {}
+    for name, lr_mult, decay_mult in paramwise_groups(named, pw, "backbone"):
+        groups.setdefault((lr_mult, decay_mult), []).append(ref_params[name])
+    assert set(groups) == {(1.0, 1.0), (1.0, 0.0), (0.1, 0.5)}
+    assert len(groups[(1.0, 0.0)]) == sum("norm" in k for k, _ in named)
+    kw = dict(lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.05)
+    o_ref = torch.optim.AdamW([dict(params=ps, lr=kw["lr"] * a, weight_decay=kw["weight_decay"] * b) for (a, b), ps in groups.items()],
+                              betas=kw["betas"], eps=kw["eps"])
+    red = GradReducer(m, pack=True)
+    flat = red.flatten_parameters(m, torch.bfloat16)
+    o_mine = FlatAdamW(flat, model=m, paramwise_cfg=pw, **kw)
+    assert o_mine.group_of is not None and len(o_mine.group_mults) == 3
+    for step in range(4):
+        red.flat.copy_(torch.randn_like(red.flat) * (0.1 + step))
+        for k, p in named:
+            ref_params[k].grad = p._grad_slot.view_as(p).clone()          # this parameter's slice of the flat gradient buffer
+        o_ref.step()
+        o_mine.step()
+        for k, p in named:
+            assert torch.allclose(p.data, ref_params[k].data, rtol=2e-6, atol=2e-7), (step, k, (p.data - ref_params[k].data).abs().max())
+    # the shadow follows the grouped update too
+    assert torch.equal(m.__dict__["_flat_pair"][1], flat.data.to(torch.bfloat16))
