@@ -37,10 +37,19 @@ def use_shipped_gemm_table(table=_TUNABLE):
     if not os.path.isfile(table) or "PYTORCH_TUNABLEOP_FILENAME" in os.environ:
         return
     import shutil
-    import tempfile
-    d = tempfile.mkdtemp(prefix="pswin_tunableop_")
+    # one deterministic cache directory (not a fresh temporary directory per import): ~/.cache, or the scratch directory of the run
+    d = os.path.join(os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache"), "pswin_tunableop")
+    try:
+        os.makedirs(d, exist_ok=True)
+    except OSError:
+        d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gpurun_out", "pswin_tunableop")
+        os.makedirs(d, exist_ok=True)
     for ordinal in range(8):
-        shutil.copyfile(table, os.path.join(d, f"tunableop_results{ordinal}.csv"))
+        dst = os.path.join(d, f"tunableop_results{ordinal}.csv")
+        if not os.path.isfile(dst) or os.path.getmtime(dst) < os.path.getmtime(table) or os.path.getsize(dst) != os.path.getsize(table):
+            tmp = f"{dst}.{os.getpid()}.tmp"
+            shutil.copyfile(table, tmp)
+            os.replace(tmp, dst)                  # atomic: the ranks of one node import this module at the same time
     os.environ.setdefault("PYTORCH_TUNABLEOP_ENABLED", "1")
     os.environ.setdefault("PYTORCH_TUNABLEOP_TUNING", "0")
     os.environ["PYTORCH_TUNABLEOP_FILENAME"] = os.path.join(d, "tunableop_results.csv")
@@ -138,6 +147,10 @@ def main():
     ap.add_argument("--height", type=int, default=512, help="panorama height; width = 2 * height (headline: 512)")
     ap.add_argument("--graph-heads", type=int, default=1, help="--config maskrcnn: capture the head stand-ins into a hipGraph too (1) or run them eagerly (0)")
     ap.add_argument("--torch-adamw", action="store_true", help="torch.optim.AdamW(fused=True) instead of the one-launch HIP update (A/B)")
+    ap.add_argument("--single-group", action="store_true", help="AdamW without the reference's parameter groups (decay on every element: A/B)")
+    ap.add_argument("--sustain-steps", type=int, default=200,
+                    help="extra steps run and timed AFTER the K timed ones (reported as sustained_ms_per_step: the clock / thermal state "
+                         "of a 0.25 s burst is not the state of a training run)")
     ap.add_argument("--backend", default=None, help="torch.distributed backend (default nccl = RCCL); 'gloo' lets two "
                     "ranks rehearse the N > 1 code path on one GPU together with --device")
     ap.add_argument("--device", type=int, default=None, help="force this HIP device index for every rank (rehearsal only)")
@@ -181,17 +194,17 @@ def main():
     from panoswintransformerobjectdetection_amd import ops as _ops
     _ops.set_deferred_reductions(not args.eager and not args.no_defer)
     reducer.broadcast_parameters(model)
-    # ONE parameter group: the optimizer runs over one flat parameter / gradient / state buffer
-    # (dp.GradReducer.flatten_parameters), i.e. a single fused element-wise launch per step.  Deviation from the reference's
-    # configs/swin/*.py, stated in the bench line: their paramwise_cfg sets decay_mult = 0 for 'norm' parameters (and for two key
-    # patterns this model does not have); same arithmetic per element and same cost, different decay on 0.2 % of the elements.
+    # The optimizer runs over ONE flat parameter / gradient / state buffer (dp.GradReducer.flatten_parameters): a single fused
+    # element-wise launch per step.  The reference's parameter groups (configs/swin/*.py paramwise_cfg: decay_mult = 0 for every
+    # parameter whose name contains 'norm') live in a byte map over that buffer (optim.FlatAdamW(paramwise_cfg=...)).
     opt_params = [reducer.flatten_parameters(model, cd if cd != torch.float32 else None)] if not args.eager else list(model.parameters())
     if args.eager or args.torch_adamw:
         opt = torch.optim.AdamW(opt_params, lr=1e-4, betas=(0.9, 0.999), weight_decay=0.05, fused=True, capturable=not args.eager)
     else:
         # the update of the flat buffer and the bf16 copy of the new weights in one HIP launch (the arithmetic of torch.optim.AdamW)
-        from panoswintransformerobjectdetection_amd.optim import FlatAdamW
-        opt = FlatAdamW(opt_params[0], lr=1e-4, betas=(0.9, 0.999), weight_decay=0.05, model=model if cd != torch.float32 else None)
+        from panoswintransformerobjectdetection_amd.optim import REFERENCE_PARAMWISE_CFG, FlatAdamW
+        opt = FlatAdamW(opt_params[0], lr=1e-4, betas=(0.9, 0.999), weight_decay=0.05, model=model,
+                        paramwise_cfg=None if args.single_group else REFERENCE_PARAMWISE_CFG)
 
     torch.manual_seed(1234 + rank)               # every rank its own shard of synthetic panoramas
     x = torch.randn(args.batch, 3, args.height, 2 * args.height, device=dev)
@@ -294,6 +307,14 @@ def main():
         loss = step()
     barrier()
     elapsed = time.perf_counter() - t0
+    sustained = None
+    if args.sustain_steps > 0:
+        # the driver's K steps last a quarter of a second; the same step for another --sustain-steps, timed the same way
+        t1 = time.perf_counter()
+        for _ in range(args.sustain_steps):
+            loss = step()
+        barrier()
+        sustained = (time.perf_counter() - t1) / args.sustain_steps * 1e3
     if not args.eager:
         # Nodes of a replayed graph cannot be bracketed by host-recorded events, so the per-kernel HIP-event timing
         # runs on eager steps of the same model / batch right after the timed region (same kernels, shapes, data).
@@ -309,9 +330,10 @@ def main():
     kern = _lib.disable_timing()
     ksteps = args.steps if args.eager else args.kernel_steps
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, sustained or 0.0], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed = float(t[0].item())
+        sustained = float(t[1].item()) if sustained is not None else None
     assert torch.isfinite(loss).item(), "non-finite loss"
     # (outside the timed region) every parameter and every gradient of the last step is finite: a finite loss alone once let
     # non-finite stem weight gradients through
@@ -394,18 +416,23 @@ def main():
                            "TFLOPs": round(sum(r[2] for r in recs) / (t_ms * 1e-3) / 1e12, 1)}
         roofline["library_gemm_pool"] = pool
         roofline["kernels"] = stats
+        roofline["kernel_timing"] = ("HIP-event pairs around each launch in eager steps after the timed region (nodes of a replayed graph cannot be "
+                                     "bracketed); the same kernels inside graph replays measure 5-12 % shorter under rocprofv3 (profiles/*_kernel_stats*), "
+                                     "so every frac here is a lower bound")
         roofline["kernel_sources_digest"] = digest
         line = {
             "metric": f"panoramas/sec PanoSwin-{args.model} {args.height}x{2 * args.height} fwd+bwd", "value": round(value, 2), "unit": "panoramas/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "sustained_ms_per_step": None if sustained is None else round(sustained, 3), "sustain_steps": args.sustain_steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": (f"PanoSwin-{args.model} backbone (embed 96, depths {'-'.join(map(str, cfg['depths']))}, "
                                     f"heads 3-6-12-24, ape, pano mode) fwd+bwd+AdamW on 3x{args.height}x{2 * args.height} "
                                     "panoramas" + (", BASELINE.json configs[1]" if (args.model, args.height) == ("T", 512) else "")),
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
                        "grad_bucket_mb": args.bucket_mb, "hip_graph": not args.eager, "overlap_allreduce": bool(split),
-                       "optimizer": "AdamW lr 1e-4 wd 0.05 over ONE flat parameter buffer (single group: unlike the reference's "
-                                    "paramwise_cfg, norm / table parameters are decayed too)",
+                       "optimizer": ("AdamW lr 1e-4 wd 0.05, one launch over the flat parameter buffer"
+                                     + (", single group (A/B)" if args.single_group or args.eager or args.torch_adamw else
+                                        ", parameter groups of the reference's paramwise_cfg (decay_mult 0 for 'norm' parameters)")),
                        "fused_window_attention": bool(_ops.FUSED_WINDOW_ATTENTION),
                        "device": torch.cuda.get_device_name(dev)},
             "roofline": roofline,
@@ -429,7 +456,7 @@ def main_maskrcnn(args):
     detached feature maps and hand their feature-map gradients to the second graph."""
     from panoswintransformerobjectdetection_amd import _lib, ops as _ops
     from panoswintransformerobjectdetection_amd.detector import MiniMaskRCNN, synthetic_targets
-    from panoswintransformerobjectdetection_amd.dp import GradReducer, init_distributed
+    from panoswintransformerobjectdetection_amd.dp import GradReducer, init_distributed, reduce_loss_scalars
     from panoswintransformerobjectdetection_amd.graph import GraphedCallable, GraphedSequence
 
     rank, local_rank, world = init_distributed(args.backend)
@@ -457,7 +484,9 @@ def main_maskrcnn(args):
     if world > 1:
         for p in head_params:
             dist.broadcast(p.data, src=0)
-    opt_bb = torch.optim.AdamW([red.flatten_parameters(bb, torch.bfloat16)], lr=1e-4, weight_decay=0.05, fused=True, capturable=True)
+    from panoswintransformerobjectdetection_amd.optim import REFERENCE_PARAMWISE_CFG, FlatAdamW
+    opt_bb = FlatAdamW(red.flatten_parameters(bb, torch.bfloat16), lr=1e-4, betas=(0.9, 0.999), weight_decay=0.05, model=bb,
+                       paramwise_cfg=REFERENCE_PARAMWISE_CFG)
     opt_hd = torch.optim.AdamW(head_params, lr=1e-4, weight_decay=0.05, fused=True)
     torch.manual_seed(1234 + rank)
     x = torch.randn(batch, 3, H, 2 * H, device=dev)
@@ -538,6 +567,10 @@ def main_maskrcnn(args):
             g_opt_hd()
         else:
             opt_hd.step()
+        if world > 1:
+            # the logged losses: BaseDetector._parse_losses all-reduces every scalar on its own (mmdet/models/detectors/base.py:213-218);
+            # here the five of them travel as ONE small all-reduce per iteration
+            losses = reduce_loss_scalars(losses)
         if record:
             ev[4].record()
             torch.cuda.synchronize()
@@ -571,8 +604,8 @@ def main_maskrcnn(args):
             "metric": f"panoramas/sec PanoSwin-T + Mask R-CNN {H}x{2 * H} end-to-end training step", "value": round(batch * world * args.steps / elapsed, 2),
             "unit": "panoramas/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"BASELINE.json configs[{2 if world == 1 else 3}]: PanoSwin-T backbone (HIP) + FPN + RPN + Mask R-CNN RoI heads (pure "
-                                   f"PyTorch stand-ins, parity unpinned), synthetic COCO-shaped targets, 3x{H}x{2 * H}, fwd + bwd + AdamW",
+            "config": {"workload": f"BASELINE.json configs[{2 if world == 1 else 3}]: PanoSwin-T backbone (HIP) + FPN + RPN + Mask R-CNN RoI heads (PyTorch "
+                                   f"stand-ins + HIP RoIAlign with the config's sampling_ratio = 0; head parity unpinned), synthetic COCO-shaped targets, 3x{H}x{2 * H}, fwd + bwd + AdamW",
                        "batch_per_gpu": batch, "global_batch": batch * world, "parallelism": f"dp{world}",
                        "device": torch.cuda.get_device_name(dev)},
             "step_breakdown_ms": {"backbone_forward_graph": round(br[0], 3), "heads_forward_backward": round(br[1], 3), "heads_in_hipgraph": graph_heads,

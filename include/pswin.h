@@ -330,6 +330,28 @@ int pswin_adamw_flat(float* p, const float* g, float* m, float* v, void* p_bf16,
 int pswin_adamw_flat_groups(float* p, const float* g, float* m, float* v, void* p_bf16, long long n, const unsigned char* group_of,
                             int n_groups, const float* lr_mult, const float* decay_mult, double lr, double beta1, double beta2, double eps,
                             double weight_decay, const float* step, void* stream);
+/* ---- the caller's side of the path: RoIAlign over an FPN pyramid ------------------------------------------------
+ * configs/_base_/models/mask_rcnn_swin_fpn.py:44-48, 63-67 (SingleRoIExtractor, RoIAlign output 7 / 14, sampling_ratio = 0, strides
+ * 4..32) and mmdet/models/roi_heads/roi_extractors/single_level_roi_extractor.py:78-108.  RoIAlign itself is mmcv.ops (not in the
+ * reference tree): the published operator is implemented (csrc/pswin_roi.hip states it); parity with the reference is unpinned.
+ * Feature maps are NHWC [B, H, W, C] (`dtype`), rois f32 [R, 5] = (batch index, x1, y1, x2, y2) in image pixels, roi_level int32 [R]
+ * = the pyramid level of every RoI (map_roi_levels, :55-60, computed by the caller), out / dout [R, P, P, C] (`dtype`).
+ * Backward ACCUMULATES (f32 atomics) into the f32 NHWC maps levels->dfeat, which the caller zeroes. */
+#define PSWIN_ROI_MAX_LEVELS 4
+typedef struct pswin_roi_levels {
+    const void* feat[PSWIN_ROI_MAX_LEVELS]; /* forward: feature maps (NULL in backward) */
+    float* dfeat[PSWIN_ROI_MAX_LEVELS];     /* backward: gradient maps (NULL in forward) */
+    int H[PSWIN_ROI_MAX_LEVELS];
+    int W[PSWIN_ROI_MAX_LEVELS];
+    float spatial_scale[PSWIN_ROI_MAX_LEVELS]; /* 1 / stride */
+    int n_levels;
+} pswin_roi_levels;
+int pswin_roi_align_supported(int C, int dtype);
+int pswin_roi_align_fwd(const pswin_roi_levels* levels, const float* rois, const int32_t* roi_level, int R, int C, int P, int sampling_ratio,
+                        int aligned, int dtype, void* out, void* stream);
+int pswin_roi_align_bwd(const pswin_roi_levels* levels, const float* rois, const int32_t* roi_level, int R, int C, int P, int sampling_ratio,
+                        int aligned, int dtype, const void* dout, void* stream);
+
 int pswin_gemm_nt_supported(long long M, int K, int N);
 int pswin_gemm_nt(const void* x, const void* w, const float* bias, void* y, long long M, int K, int N, int tile_m, void* stream);
 /* The data gradient of the Mlp's fc2 fused with the backward of fc1's bias + nn.GELU (HOT:50-58):

@@ -63,6 +63,9 @@ _PROTOTYPES = {
     "pswin_adamw_flat": [_vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _vp, _vp],
     "pswin_adamw_flat_groups": [_vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _vp, _i, _vp, _vp, ctypes.c_double, ctypes.c_double,
                                 ctypes.c_double, ctypes.c_double, ctypes.c_double, _vp, _vp],
+    "pswin_roi_align_supported": [_i, _i],
+    "pswin_roi_align_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "pswin_roi_align_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "pswin_gemm_nt_supported": [ctypes.c_longlong, _i, _i],
     "pswin_gemm_nt": [_vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _i, _vp],
     "pswin_gemm_nt_gelu_fwd": [_vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _i, _vp],
@@ -119,6 +122,12 @@ class ReduceJob(ctypes.Structure):
 class TransposeJob(ctypes.Structure):
     """pswin_transpose_job of include/pswin.h"""
     _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("rows", ctypes.c_int), ("cols", ctypes.c_int)]
+
+
+class RoiLevels(ctypes.Structure):
+    """pswin_roi_levels of include/pswin.h"""
+    _fields_ = [("feat", ctypes.c_void_p * 4), ("dfeat", ctypes.c_void_p * 4), ("H", ctypes.c_int * 4), ("W", ctypes.c_int * 4),
+                ("spatial_scale", ctypes.c_float * 4), ("n_levels", ctypes.c_int)]
 
 
 class TableGradJob(ctypes.Structure):

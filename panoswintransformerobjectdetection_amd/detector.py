@@ -12,9 +12,10 @@ the reference's configuration numbers (configs/_base_/models/mask_rcnn_swin_fpn.
   channel), called as TwoStageDetector.forward_train does (mmdet/models/detectors/two_stage.py:116-175).
 
 PARITY: unpinned.  The reference tree does not contain mmcv.ops (RoIAlign, NMS CUDA sources) nor a fixture for any head,
-so nothing here is checked against reference outputs; RoIAlign samples a fixed 2 x 2 grid per bin (the config's
-sampling_ratio = 0 is adaptive) and NMS is the exact greedy rule evaluated as a fixed-point iteration on the GPU.  The heads
-run as ordinary PyTorch-ROCm operators (MIOpen / hipBLASLt, bf16 autocast); only the backbone is hand-written HIP.
+so nothing here is checked against reference outputs.  RoIAlign is the published operator with the config's sampling_ratio = 0
+(adaptive grid) as hand-written HIP kernels, forward and backward (csrc/pswin_roi.hip, checked against a plain PyTorch statement
+of the definition in tests/); NMS is the greedy rule evaluated as a fixed-point iteration on the GPU (see nms_keep).  The other
+head operators are ordinary PyTorch-ROCm operators (MIOpen / hipBLASLt, bf16 autocast).
 """
 import math
 
@@ -74,7 +75,9 @@ def decode_deltas(src, deltas, stds, max_shape):
 def nms_keep(boxes, iou_thr, iters=12):
     """Greedy NMS on score-sorted boxes as a fixed point: keep[j] = not any(i < j: keep[i] and IoU(i, j) > thr).  Starting
     from "keep all", every sweep fixes at least one more level of the suppression chains; `iters` sweeps of one [n, n]
-    mask-vector product each, no host synchronisation."""
+    mask-vector product each, no host synchronisation (the step is captured in a hipGraph: a static sweep count).  Exact
+    when no suppression chain is deeper than `iters`; APPROXIMATE beyond that (the default 12 is not checked for convergence
+    in the step; tests/test_detector_heads.py compares 32 sweeps with the sequential rule)."""
     over = torch.triu(box_iou(boxes, boxes) > iou_thr, diagonal=1).float()
     keep = torch.ones(boxes.shape[0], device=boxes.device)
     for _ in range(iters):
@@ -163,36 +166,16 @@ class MaskHead(nn.Module):
         return self.logits(F.relu(self.up(x)))
 
 
-def roi_align(feats, strides, rois, out_size, finest_scale=56, samples=2):
-    """SingleRoIExtractor + RoIAlign over 4 FPN levels.  rois [B, n, 4] in image pixels (the same number per image) ->
-    [B * n, C, out, out].  One grid_sample per level over the whole batch; a fixed samples x samples grid per output bin,
-    averaged; every RoI takes its value from the level its scale maps to (finest_scale = 56, as mmdet)."""
+def roi_align(feats, strides, rois, out_size, finest_scale=56, sampling_ratio=0):
+    """SingleRoIExtractor + RoIAlign(output_size, sampling_ratio = 0: adaptive ceil(roi / output) samples per bin) over 4 FPN levels
+    (configs/_base_/models/mask_rcnn_swin_fpn.py:44-48, 63-67).  rois [B, n, 4] in image pixels (the same number per image) ->
+    [B * n, C, out, out].  One HIP kernel per direction (ops.roi_align_fpn -> pswin_roi_align_fwd / _bwd): every RoI is sampled on
+    the level its scale maps to (finest_scale = 56, as mmdet) and only there."""
+    from . import ops
     B, n, _ = rois.shape
-    scale = torch.sqrt(((rois[..., 2] - rois[..., 0]) * (rois[..., 3] - rois[..., 1])).clamp(min=1e-6))
-    lvl = torch.floor(torch.log2(scale / finest_scale + 1e-6)).clamp(0, len(feats) - 1).long()      # [B, n]
-    S = out_size * samples
-    t = (torch.arange(S, device=rois.device, dtype=torch.float32) + 0.5) / S                      # sample positions in [0, 1]
-    out = None
-    for l, (f, s) in enumerate(zip(feats, strides)):
-        _, C, H, W = f.shape
-        x1, y1, x2, y2 = [rois[..., i] / s for i in range(4)]
-        gx = (x1[..., None] + (x2 - x1).clamp(min=1.0)[..., None] * t) / W * 2 - 1                # [B, n, S]
-        gy = (y1[..., None] + (y2 - y1).clamp(min=1.0)[..., None] * t) / H * 2 - 1
-        # Border replication for the RoIs of this level (clamping the sample centres half a pixel inside the map is the same thing),
-        # and the RoIs of OTHER levels pushed outside the map with zero padding: they then read zeros and, in the backward pass,
-        # scatter nothing -- sampled on every level and masked afterwards, four fifths of grid_sample's atomic adds carried zeros
-        gx = gx.clamp(-1 + 1.0 / W, 1 - 1.0 / W)
-        gy = gy.clamp(-1 + 1.0 / H, 1 - 1.0 / H)
-        sel = (lvl == l)[..., None]
-        gx = torch.where(sel, gx, gx.new_full((), 3.0))
-        gy = torch.where(sel, gy, gy.new_full((), 3.0))
-        grid = torch.stack([gx[:, :, None, :].expand(B, n, S, S), gy[:, :, :, None].expand(B, n, S, S)], -1).reshape(B, n * S, S, 2)
-        # sampled in fp32: the backward pass of grid_sample scatters with atomic adds, which are native for f32 and a
-        # compare-and-swap loop for bf16 (16.6 ms per launch, ~100 ms of a 133 ms head step on MI355X)
-        smp = F.grid_sample(f.float(), grid.float(), mode="bilinear", padding_mode="zeros", align_corners=False).to(f.dtype)   # [B, C, n*S, S]
-        smp = F.avg_pool2d(smp.view(B, C, n, S, S).permute(0, 2, 1, 3, 4).reshape(B * n, C, S, S), samples)
-        out = smp if out is None else out + smp
-    return out
+    bidx = torch.arange(B, device=rois.device, dtype=rois.dtype)[:, None, None].expand(B, n, 1)
+    rois5 = torch.cat([bidx, rois], -1).reshape(B * n, 5)
+    return ops.roi_align_fpn(list(feats), strides, rois5, out_size, sampling_ratio, True, finest_scale)
 
 
 # ------------------------------------------------------------------------------------------------------------------------
@@ -203,6 +186,8 @@ class MiniMaskRCNN(nn.Module):
     `heads_loss(feats, targets)` is everything behind the backbone; `forward_train` = backbone + heads_loss."""
 
     STRIDES = (4, 8, 16, 32, 64)
+    rand_like = staticmethod(torch.rand_like)    # the samplers' random keys (tests substitute a fixed sequence to compare eager and replayed steps)
+    roi_align = staticmethod(roi_align)          # the HIP operator; tests of the head stand-ins on the CPU substitute the PyTorch statement
 
     def __init__(self, backbone_cfg, num_classes=80):
         super().__init__()
@@ -246,7 +231,7 @@ class MiniMaskRCNN(nn.Module):
             lq = ((iou == gbest[None]) & (gbest[None] >= cfg["min_pos"])).any(1)
             label[lq] = 1
             # random sampling with static shapes: rank by a random key, positives first
-            key = torch.rand_like(best)
+            key = self.rand_like(best)
             pos_rank = torch.argsort(torch.where(label == 1, key, key + 2))[:n_pos_max]
             pos_valid = label[pos_rank] == 1
             neg_rank = torch.argsort(torch.where(label == 0, key, key + 2))[:n_tot]
@@ -289,10 +274,15 @@ class MiniMaskRCNN(nn.Module):
                 iou = box_iou(cand, gt)
                 best, arg = iou.max(1)
                 is_pos = best >= cfg["pos"]
-                key = torch.rand_like(best)
+                key = self.rand_like(best)
                 pos_rank = torch.argsort(torch.where(is_pos, key, key + 2))[:n_pos_max]
                 pos_valid = is_pos[pos_rank]
-                neg_rank = torch.argsort(torch.where(~is_pos, key, key + 2))[:n_tot - n_pos_max]
+                # the positive slots that found no positive were filled with the lowest-key non-positives (they count as background
+                # below): the negatives proper are the NEXT ones in that order, so that no RoI is sampled twice
+                filler = n_pos_max - pos_valid.sum()
+                neg_order = torch.argsort(torch.where(~is_pos, key, key + 2))
+                take = (torch.arange(n_tot - n_pos_max, device=key.device) + filler).clamp(max=neg_order.numel() - 1)
+                neg_rank = neg_order[take]
                 idx = torch.cat([pos_rank, neg_rank])
                 rois.append(cand[idx])
                 lab = torch.where(torch.cat([pos_valid, torch.zeros_like(neg_rank, dtype=torch.bool)]), gl[arg[idx]],
@@ -303,7 +293,7 @@ class MiniMaskRCNN(nn.Module):
                 gt_idx_all.append(arg[pos_rank])
         rois_b, labels_c = torch.stack(rois), torch.cat(labels)                                  # [B, n_tot, 4], [B * n_tot]
         B = len(proposals)
-        x = roi_align(feats[:4], self.STRIDES[:4], rois_b, 7)
+        x = self.roi_align(feats[:4], self.STRIDES[:4], rois_b, 7)
         cls, reg = self.bbox_head(x.to(feats[0].dtype))
         loss_cls = F.cross_entropy(cls.float(), labels_c)
         pos_sel = torch.cat([torch.arange(n_pos_max, device=rois_b.device) + b * n_tot for b in range(B)])
@@ -313,7 +303,7 @@ class MiniMaskRCNN(nn.Module):
         reg_p = reg.float()[pos_sel].view(-1, self.num_classes, 4)[ar, pl]
         loss_bbox = ((reg_p - torch.cat(reg_t)).abs().sum(1) * pv).sum() / (B * n_tot)
         # masks on the positive RoIs (the first n_pos_max of every image)
-        xm = roi_align(feats[:4], self.STRIDES[:4], rois_b[:, :n_pos_max], 14)
+        xm = self.roi_align(feats[:4], self.STRIDES[:4], rois_b[:, :n_pos_max], 14)
         logits = self.mask_head(xm.to(feats[0].dtype)).float()                                    # [B * P, classes, 28, 28]
         logit_c = logits[ar, pl]
         with torch.no_grad():

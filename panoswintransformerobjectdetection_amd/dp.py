@@ -268,3 +268,16 @@ def backward_early(loss_early, xb, g_xb, early_params):
                                 grad_outputs=[torch.ones_like(loss_early), g_xb], allow_unused=True)
     for p, g in zip(early_params, grads):
         p.grad = g
+
+
+def reduce_loss_scalars(losses, group=None):
+    """The logged losses of one iteration averaged over the ranks with ONE small all-reduce.  The reference's
+    BaseDetector._parse_losses (mmdet/models/detectors/base.py:213-218) issues one all-reduce per scalar (6-10 launches per
+    iteration, each a latency-bound collective); same result: ``{name: mean over ranks of the local value}`` in sorted-key order.
+    A no-op copy on one rank."""
+    keys = sorted(losses)
+    vals = torch.stack([losses[k].detach().float().reshape(()) for k in keys])
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(vals, op=dist.ReduceOp.SUM, group=group)
+        vals = vals / dist.get_world_size(group)
+    return dict(zip(keys, vals.unbind()))

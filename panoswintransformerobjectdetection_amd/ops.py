@@ -1307,3 +1307,66 @@ def window_attention_fused(x2d, attn, dist, mask, n_bias_windows):
                                        _as_tiles(dist), _as_tiles(mask), attn.num_heads, attn.scale, n_bias_windows,
                                        lq[0] if lq is not None else None, lp[0] if lp is not None else None,
                                        torch.is_grad_enabled())
+
+
+# ------------------------------------------------------------------------------------------------
+# the caller's side: RoIAlign over the FPN pyramid
+# ------------------------------------------------------------------------------------------------
+def _roi_levels(ptrs_fwd, ptrs_bwd, shapes, strides):
+    lv = _lib.RoiLevels()
+    lv.n_levels = len(shapes)
+    for l, ((H, W), s) in enumerate(zip(shapes, strides)):
+        lv.feat[l] = ptrs_fwd[l] if ptrs_fwd else None
+        lv.dfeat[l] = ptrs_bwd[l] if ptrs_bwd else None
+        lv.H[l], lv.W[l], lv.spatial_scale[l] = H, W, 1.0 / s
+    return lv
+
+
+class _RoiAlignFPN(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, rois, roi_level, P, sampling_ratio, aligned, strides, *feats):
+        import ctypes
+        C = feats[0].shape[1]
+        dt = feats[0].dtype
+        if len(feats) > 4 or any(f.dtype != dt or f.shape[1] != C or f.dim() != 4 for f in feats):
+            raise PswinError("roi_align_fpn: up to four NCHW maps of one dtype and channel count")
+        if not _lib.load().pswin_roi_align_supported(C, dtype_code(feats[0])):
+            raise PswinError(f"roi_align_fpn: unsupported channel count {C} for {dt}")
+        nhwc = [f.permute(0, 2, 3, 1).contiguous() for f in feats]          # a pixel's channels = one contiguous row
+        rois = rois.detach().float().contiguous()
+        roi_level = roi_level.to(torch.int32).contiguous()
+        R = rois.shape[0]
+        out = torch.empty(R, P, P, C, dtype=dt, device=rois.device)
+        shapes = [tuple(f.shape[2:]) for f in feats]
+        lv = _roi_levels([f.data_ptr() for f in nhwc], None, shapes, strides)
+        call("pswin_roi_align_fwd", out, ctypes.byref(lv), ptr(rois), ptr(roi_level), R, C, P, int(sampling_ratio), int(aligned),
+             dtype_code(out), ptr(out))
+        ctx.save_for_backward(rois, roi_level)
+        ctx.cfg = (P, int(sampling_ratio), int(aligned), tuple(strides), shapes, [f.shape[0] for f in feats], C, dt)
+        return out.permute(0, 3, 1, 2)                                      # [R, C, P, P] (channels-last in memory)
+
+    @staticmethod
+    def backward(ctx, dout):
+        import ctypes
+        rois, roi_level = ctx.saved_tensors
+        P, sr, aligned, strides, shapes, batches, C, dt = ctx.cfg
+        d = dout.permute(0, 2, 3, 1).to(dt).contiguous()                    # [R, P, P, C]
+        grads = [torch.zeros(b, H, W, C, dtype=torch.float32, device=d.device) for b, (H, W) in zip(batches, shapes)]
+        lv = _roi_levels(None, [g.data_ptr() for g in grads], shapes, strides)
+        call("pswin_roi_align_bwd", d, ctypes.byref(lv), ptr(rois), ptr(roi_level), rois.shape[0], C, P, sr, aligned, dtype_code(d), ptr(d))
+        return (None, None, None, None, None, None) + tuple(g.permute(0, 3, 1, 2).to(dt) for g in grads)
+
+
+def map_roi_levels(rois, num_levels, finest_scale=56):
+    """SingleRoIExtractor.map_roi_levels (mmdet/models/roi_heads/roi_extractors/single_level_roi_extractor.py:55-60): rois [R, 5]."""
+    scale = torch.sqrt((rois[:, 3] - rois[:, 1]) * (rois[:, 4] - rois[:, 2]))
+    return torch.floor(torch.log2(scale / finest_scale + 1e-6)).clamp(min=0, max=num_levels - 1).long()
+
+
+def roi_align_fpn(feats, strides, rois, out_size, sampling_ratio=0, aligned=True, finest_scale=56, roi_level=None):
+    """SingleRoIExtractor(RoIAlign(out_size, sampling_ratio)) over up to four NCHW pyramid levels (single_level_roi_extractor.py:78-108,
+    configs/_base_/models/mask_rcnn_swin_fpn.py:44-48): rois [R, 5] = (batch index, x1, y1, x2, y2) in image pixels -> [R, C, out, out].
+    Forward and backward are HIP kernels (pswin_roi_align_fwd / _bwd); only the feature maps receive a gradient."""
+    if roi_level is None:
+        roi_level = map_roi_levels(rois, len(feats), finest_scale)
+    return _RoiAlignFPN.apply(rois, roi_level, int(out_size), sampling_ratio, aligned, tuple(strides), *feats)

@@ -32,3 +32,11 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    """The product's operator module (ctypes over libpswin_hip.so) with its shape caches cleared."""
+    import panoswintransformerobjectdetection_amd as pkg
+    pkg.ops.clear_caches()
+    return pkg.ops

@@ -5,6 +5,8 @@ import torch
 
 from panoswintransformerobjectdetection_amd import detector as det
 
+import _roi_ref
+
 
 def _greedy_nms(boxes, thr):
     keep = []
@@ -40,25 +42,34 @@ def test_delta_coder_round_trip_and_anchor_layout():
     assert torch.allclose((anc[3:6, :2] + anc[3:6, 2:]) / 2, torch.tensor([[4.0, 0.0]] * 3))    # location-major, x fastest
 
 
-def test_roi_align_reproduces_a_linear_ramp():
+def test_roi_align_statement_reproduces_a_linear_ramp():
+    """The PyTorch statement of RoIAlign (tests/_roi_ref.py, the checker of the HIP kernels): bilinear sampling is exact on a linear
+    ramp, so every bin of an interior RoI returns the ramp at the bin centre (aligned = True: pixel centres at integer + 0.5)."""
     B, C, H, W = 2, 3, 16, 32
     ys, xs = torch.meshgrid(torch.arange(H).float(), torch.arange(W).float(), indexing="ij")
     f = torch.stack([xs, ys, torch.ones_like(xs)])[None].repeat(B, 1, 1, 1)                      # channels: x, y, 1 at pixel centres
     feats = [f, f[:, :, ::2, ::2], f[:, :, ::4, ::4], f[:, :, ::8, ::8]]
     rois = torch.tensor([[[8., 8., 40., 24.], [20., 12., 60., 44.]]] * B)                         # image pixels, stride 4 level
-    out = det.roi_align(feats, (4, 8, 16, 32), rois, 2, finest_scale=56)
+    out = _roi_ref.roi_align_batched(feats, (4, 8, 16, 32), rois, 2, finest_scale=56)
     assert out.shape == (B * 2, C, 2, 2)
-    # small RoIs map to level 0 (stride 4): bin centres in feature coordinates minus the half-pixel of align_corners=False
     x1, y1, x2, y2 = 2.0, 2.0, 10.0, 6.0
     want_x = torch.tensor([x1 + (x2 - x1) * 0.25, x1 + (x2 - x1) * 0.75]) - 0.5
     want_y = torch.tensor([y1 + (y2 - y1) * 0.25, y1 + (y2 - y1) * 0.75]) - 0.5
     assert torch.allclose(out[0, 0, 0], want_x, atol=1e-4) and torch.allclose(out[0, 1, :, 0], want_y, atol=1e-4)
     assert torch.allclose(out[:, 2], torch.ones(B * 2, 2, 2), atol=1e-5)
+    # adaptive grid: an 8 x 4-cell RoI pooled to 2 x 2 takes ceil(4 / 2) x ceil(8 / 2) = 2 x 4 samples per bin; a fixed 1 x 1 grid
+    # differs on a non-linear map, the adaptive one equals the mean over its sub-bin centres
+    g = torch.rand(1, 1, 16, 32)
+    r5 = torch.tensor([[0., 8., 8., 40., 24.]])
+    a = _roi_ref.roi_align_fpn([g], (4,), r5, 2, sampling_ratio=0)
+    b = _roi_ref.roi_align_fpn([g], (4,), r5, 2, sampling_ratio=1)
+    assert not torch.allclose(a, b)
 
 
 def test_heads_training_step_is_finite_and_reaches_every_parameter():
     torch.manual_seed(0)
     m = det.MiniMaskRCNN(dict(embed_dim=96, depths=[2, 2, 2, 2], num_heads=[3, 6, 12, 24], ape=True), num_classes=80)
+    m.roi_align = _roi_ref.roi_align_batched          # CPU: the PyTorch statement stands in for the HIP operator (GPU: tests/test_roi_gpu.py)
     B, H, W = 2, 128, 256
     feats = [torch.randn(B, c, H // s, W // s, requires_grad=True) for c, s in zip((96, 192, 384, 768), (4, 8, 16, 32))]
     tg = det.synthetic_targets(B, H, W, "cpu")

@@ -16,13 +16,6 @@ PANO_CASES = [(128, 256), (64, 128), (32, 64), (16, 32), (13, 25), (25, 49), (50
 PLANAR_CASES = [(16, 32), (15, 31), (128, 256), (20, 33), (15, 25)]
 
 
-@pytest.fixture(scope="module")
-def ops():
-    import panoswintransformerobjectdetection_amd as pkg
-    pkg.ops.clear_caches()
-    return pkg.ops
-
-
 DEV = "cuda:0"
 
 
