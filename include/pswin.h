@@ -302,6 +302,15 @@ int pswin_gemm_tn_supported(long long M, int N, int K);
 int pswin_gemm_tn_splits(long long M, int N, int K);
 int pswin_gemm_tn(const void* dy, const void* x, float* partial, long long M, int N, int K, int splits, void* stream);
 
+/* The same product with a three-stage LDS ring (counted waits, one raw barrier per 64-row slab, one 8-wave workgroup per CU):
+ * csrc/pswin_gemm_tn.hip, "Round 3".  One macro tile of 192 x 192 serves every Linear of the model (N % 192 == 0, K % 192 == 0).
+ * partial: [splits, N, K] in `partial_dtype` (PSWIN_F32, or PSWIN_BF16 = each split's tile rounded once, as the library's batched GEMM
+ * does for its row chunks); 1 <= splits <= M / 64; pswin_gemm_tn_ring_splits(M, N, K, target_wgs) suggests a split count for about
+ * target_wgs workgroups (0 = 256: one per CU). */
+int pswin_gemm_tn_ring_supported(long long M, int N, int K);
+int pswin_gemm_tn_ring_splits(long long M, int N, int K, int target_wgs);
+int pswin_gemm_tn_ring(const void* dy, const void* x, void* partial, int partial_dtype, long long M, int N, int K, int splits, void* stream);
+
 typedef struct pswin_transpose_job {
     const void* src; /* bf16 [rows][cols] */
     void* dst;       /* bf16 [cols][rows] */

@@ -59,6 +59,9 @@ _PROTOTYPES = {
     "pswin_gemm_tn_supported": [ctypes.c_longlong, _i, _i],
     "pswin_gemm_tn_splits": [ctypes.c_longlong, _i, _i],
     "pswin_gemm_tn": [_vp, _vp, _vp, ctypes.c_longlong, _i, _i, _i, _vp],
+    "pswin_gemm_tn_ring_supported": [ctypes.c_longlong, _i, _i],
+    "pswin_gemm_tn_ring_splits": [ctypes.c_longlong, _i, _i, _i],
+    "pswin_gemm_tn_ring": [_vp, _vp, _vp, _i, ctypes.c_longlong, _i, _i, _i, _vp],
     "pswin_transpose_jobs": [_vp, _i, _vp],
     "pswin_adamw_flat": [_vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _vp, _vp],
     "pswin_adamw_flat_groups": [_vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _vp, _i, _vp, _vp, ctypes.c_double, ctypes.c_double,

@@ -19,6 +19,8 @@
 //     its f32 partial tile [split][N][K] once with 16-byte stores (the product is computed as X^T . dY so that a lane owns 4
 //     consecutive k of one row n) and the caller sums the splits in its fixed-order grouped reduction (pswin_reduce_jobs)
 //     straight into the flat gradient buffer -- no atomics, bitwise reproducible.
+#include <type_traits>
+
 #include "pswin_common.hpp"
 
 using namespace pswin;
@@ -149,6 +151,203 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(const unsigned s
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 3: the same product with a THREE-stage LDS ring.  The contraction of a weight gradient is long (256 - 2,400 rows per
+// split = 4 - 37 slabs), so unlike the forward GEMMs (3 - 12 k-steps per tile) a deep pipeline reaches steady state: the slabs of
+// steps t + 1 and t + 2 are in flight while step t is multiplied, the wait in front of a step is a COUNTED vmcnt that leaves the
+// younger slab's LDS-DMA outstanding, and the one barrier per step is a raw s_barrier (a __syncthreads() would drain vmcnt to 0:
+// cdna_hip_programming.md, "Pipelining across barriers").  One workgroup of 8 waves per CU (2 waves per SIMD), macro tile
+// 192 (k) x 192 (n) -- every N and K of the model is a multiple of 192, so one kernel serves every layer, the stage-1 qkv / proj
+// pair included -- waves as 2 (k) x 4 (n), 18 accumulator quads and 36 MFMAs per wave and slab; ring = 3 x 6 panels = 144 KB.
+// OUT_BF16: the split's partial tile is rounded to bf16 (what the library's batched GEMM writes for its row chunks) -- half the
+// partial-slab traffic of the f32 form, same fixed-order f32 sum of the splits afterwards.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int RING_THREADS = 512, RING_STAGES = 3, RING_PANELS = 6, RING_STAGE_BYTES = RING_PANELS * PANEL;
+
+// The transposed LDS reads of the ring kernel are inline asm: hipcc (ROCm 7.2) treats the ds_read_tr16 builtin as possibly aliasing
+// every LDS-DMA in flight and puts `s_waitcnt vmcnt(0)` in front of the first read of each step (seen in the ISA with either LDS-DMA
+// builtin) -- which drains the ring.  An asm read is invisible to that pass; its completion is counted by hand: every destination is
+// an in-out operand of the wait statement that follows, so no use (or copy) of it can be scheduled in front of the wait
+// (cdna_hip_programming.md 5.7, form (ii)).
+template <int OFF>
+__device__ inline void ds_tr(u32x2& dst, unsigned addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF) : "memory");
+}
+struct Frag {
+    u32x2 lo, hi;                                       // rows m .. m+3 / m+4 .. m+7 of the lane's column
+};
+__device__ inline bf16x8 frag_bf16(const Frag& f) { return __builtin_bit_cast(bf16x8, u32x4{f.lo[0], f.lo[1], f.hi[0], f.hi[1]}); }
+// wait for every LDS read issued so far; the 9 fragments ride along as in-out operands (18 registers pairs per statement)
+__device__ inline void wait_frags(Frag (&a)[6], Frag (&b)[3]) {
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(a[0].lo), "+v"(a[0].hi), "+v"(a[1].lo), "+v"(a[1].hi), "+v"(a[2].lo), "+v"(a[2].hi), "+v"(a[3].lo), "+v"(a[3].hi),
+                   "+v"(a[4].lo), "+v"(a[4].hi), "+v"(a[5].lo), "+v"(a[5].hi), "+v"(b[0].lo), "+v"(b[0].hi), "+v"(b[1].lo), "+v"(b[1].hi),
+                   "+v"(b[2].lo), "+v"(b[2].hi)
+                 :
+                 : "memory");
+}
+
+template <bool OUT_BF16>
+__global__ __launch_bounds__(RING_THREADS, 2) void gemm_tn_ring_kernel(const unsigned short* __restrict__ DY, const unsigned short* __restrict__ X,
+                                                                        void* __restrict__ P, int M, int N, int K, int tiles_k, int tiles_n,
+                                                                        int rows_per_split) {
+    constexpr int IA = 6, JB = 3;                      // 16-wide tiles per wave along k (96 columns) / n (48 columns)
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int c = lane & 15, g = lane >> 4;
+    const int wk = wave >> 2, wn = wave & 3;
+
+    const int ntiles = tiles_k * tiles_n, nwg = gridDim.x;
+    int t;
+    {
+        const int bid = blockIdx.x, q = nwg / 8, r = nwg % 8, xcd = bid % 8, loc = bid / 8;
+        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+    }
+    const int split = t / ntiles, tile = t - split * ntiles;
+    const int tk = tile / tiles_n, tn = tile - tk * tiles_n;
+    const int k0 = tk * 192, n0 = tn * 192;
+    const int m_begin = split * rows_per_split;
+    int steps = rows_per_split / MSTEP;
+    {
+        const int left = (M - m_begin + MSTEP - 1) / MSTEP;           // slabs that hold at least one real row
+        steps = left < steps ? (left > 0 ? left : 0) : steps;
+    }
+
+    // LDS-DMA: 48 row blocks (8 rows x 128 B) per slab: waves 0-3 bring the 24 blocks of the three X panels, waves 4-7 those of the
+    // three dY panels, 6 wave instructions each; rows past M read as zeros (buffer range check)
+    const bool mine_x = wave < 4;
+    const rsrc_t src = mine_x ? __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(X), 0, (int)((size_t)M * K * 2), 0x00020000)
+                              : __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(DY), 0, (int)((size_t)M * N * 2), 0x00020000);
+    const unsigned ld2 = (unsigned)((mine_x ? K : N) * 2);
+    const int c0 = mine_x ? k0 : n0;
+    const int lr = lane >> 3, pch = lane & 7;
+    unsigned goff[6];                                   // byte offset of this lane's 16 bytes, relative to row m of the slab
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int blk_all = (wave & 3) * 6 + j, panel = blk_all >> 3, blk = blk_all & 7;
+        const int row = 8 * blk + lr;
+        const int f = ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
+        const int col = (((pch >> 1) ^ f) << 4) + ((pch & 1) << 3);
+        goff[j] = (unsigned)row * ld2 + (unsigned)((c0 + 64 * panel + col) * 2);
+    }
+    auto issue = [&](int step, int stage) {
+        char* base = smem + stage * RING_STAGE_BYTES + wave * 6 * 1024;
+        const unsigned m = (unsigned)(m_begin + step * MSTEP) * ld2;
+#pragma unroll
+        for (int j = 0; j < 6; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(src, (lds_void*)(base + j * 1024), 16, goff[j] + m, 0, 0, 0);
+    };
+
+    f32x4 acc[IA][JB];
+#pragma unroll
+    for (int i = 0; i < IA; ++i)
+#pragma unroll
+        for (int j = 0; j < JB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // transposed reads: lane (c = 4 q + p, g) addresses row (32 ks + 8 g + q), 8-byte piece p of the 16-column block cb of a panel;
+    // block swizzle f = ((q >> 1) & 1) | ((g & 1) << 1) is a lane constant.  One base register per 16-column block position cb and
+    // immediate offsets for panel, ks and the second row quad.
+    const int q = c >> 2, p8 = c & 3;
+    const int fl = ((q >> 1) & 1) | ((g & 1) << 1);
+    const unsigned lds0 = (unsigned)(size_t)(lds_void*)smem;
+    const unsigned lane_row = lds0 + (unsigned)((8 * g + q) * 128 + p8 * 8);
+    unsigned xoff[4];
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) xoff[cb] = ((unsigned)(cb ^ fl) << 5) + lane_row;
+    // column block of fragment i (k side) / j (n side) of this wave: col0 = 96 wk + 16 i -> panel col0 >> 6, cb = (col0 >> 4) & 3
+    // wk, wn are wave-uniform but not compile-time: the panel part goes into the base register, the rest are immediates
+    unsigned abase[IA], bbase[JB];
+#pragma unroll
+    for (int i = 0; i < IA; ++i) {
+        const int col0 = wk * 96 + 16 * i;
+        abase[i] = xoff[(col0 >> 4) & 3] + (unsigned)((col0 >> 6) * PANEL);
+    }
+#pragma unroll
+    for (int j = 0; j < JB; ++j) {
+        const int col0 = wn * 48 + 16 * j;
+        bbase[j] = xoff[(col0 >> 4) & 3] + (unsigned)((col0 >> 6) * PANEL + 3 * PANEL);
+    }
+    auto read_set = [&](unsigned stage_off, auto ks_tag, Frag (&a)[6], Frag (&b)[3]) {
+        constexpr int KS = decltype(ks_tag)::value;
+#pragma unroll
+        for (int i = 0; i < IA; ++i) {
+            ds_tr<KS * 4096>(a[i].lo, abase[i] + stage_off);
+            ds_tr<KS * 4096 + 512>(a[i].hi, abase[i] + stage_off);
+        }
+#pragma unroll
+        for (int j = 0; j < JB; ++j) {
+            ds_tr<KS * 4096>(b[j].lo, bbase[j] + stage_off);
+            ds_tr<KS * 4096 + 512>(b[j].hi, bbase[j] + stage_off);
+        }
+    };
+    auto mma_set = [&](Frag (&a)[6], Frag (&b)[3]) {
+        bf16x8 af[IA], bfr[JB];
+#pragma unroll
+        for (int i = 0; i < IA; ++i) af[i] = frag_bf16(a[i]);
+#pragma unroll
+        for (int j = 0; j < JB; ++j) bfr[j] = frag_bf16(b[j]);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int j = 0; j < JB; ++j)
+#pragma unroll
+            for (int i = 0; i < IA; ++i) acc[i][j] = mfma32(af[i], bfr[j], acc[i][j]);      // rows = k, columns = n
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    if (steps > 0) issue(0, 0);
+    if (steps > 1) issue(1, 1);
+    int stage = 0;
+    for (int st = 0; st < steps; ++st) {
+        // slab st has landed for this wave once at most the 6 younger LDS-DMA instructions (slab st + 1) are outstanding; the barrier
+        // then says so for every wave, and that every wave is done reading slab st - 1, whose stage the next issue overwrites
+        if (st + 1 < steps) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const unsigned stage_off = (unsigned)(stage * RING_STAGE_BYTES);
+        Frag a0[6], b0[3], a1[6], b1[3];
+        read_set(stage_off, std::integral_constant<int, 0>{}, a0, b0);
+        if (st + 2 < steps) issue(st + 2, stage == 0 ? 2 : stage - 1);       // (stage + 2) % 3
+        wait_frags(a0, b0);
+        read_set(stage_off, std::integral_constant<int, 1>{}, a1, b1);       // the second 32-row half flies under the first half's MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        mma_set(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        wait_frags(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_set(a1, b1);
+        stage = stage == 2 ? 0 : stage + 1;
+    }
+
+    // acc[i][j][e] = partial dW[n = n0 + 48 wn + 16 j + c][k = k0 + 96 wk + 16 i + 4 g + e]
+#pragma unroll
+    for (int j = 0; j < JB; ++j) {
+        const int n = n0 + wn * 48 + 16 * j + c;
+#pragma unroll
+        for (int i = 0; i < IA; ++i) {
+            const int k = k0 + wk * 96 + 16 * i + 4 * g;
+            const size_t o = (size_t)split * N * K + (size_t)n * K + k;
+            if constexpr (OUT_BF16) {
+                *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(P) + o) = u32x2{pack2_bf16(acc[i][j][0], acc[i][j][1]), pack2_bf16(acc[i][j][2], acc[i][j][3])};
+            } else {
+                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(P) + o) = acc[i][j];
+            }
+        }
+    }
+}
+
+template <bool OUT_BF16>
+int launch_tn_ring(const void* dy, const void* x, void* partial, int M, int N, int K, int splits, hipStream_t st) {
+    constexpr size_t lds = (size_t)RING_STAGES * RING_STAGE_BYTES;
+    static std::atomic<unsigned long long> configured{0};
+    if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&gemm_tn_ring_kernel<OUT_BF16>), lds, configured)) return rc;
+    const int tiles_k = K / 192, tiles_n = N / 192;
+    const int rows_per_split = ((M + splits - 1) / splits + MSTEP - 1) / MSTEP * MSTEP;
+    hipLaunchKernelGGL((gemm_tn_ring_kernel<OUT_BF16>), dim3(tiles_k * tiles_n * splits), dim3(RING_THREADS), lds, st,
+                       reinterpret_cast<const unsigned short*>(dy), reinterpret_cast<const unsigned short*>(x), partial, M, N, K, tiles_k, tiles_n,
+                       rows_per_split);
+    PSWIN_LAUNCH_RET();
+}
+
 template <int PA, int PB>
 int launch_tn(const void* dy, const void* x, float* partial, int M, int N, int K, int splits, hipStream_t st) {
     constexpr size_t lds = 2 * (size_t)(PA + PB) * PANEL;
@@ -187,6 +386,28 @@ int pswin_gemm_tn_splits(long long M, int N, int K) {
     const int smax = (int)(M / 256) > 0 ? (int)(M / 256) : 1;
     if (s > smax) s = smax;
     return s < 1 ? 1 : s;
+}
+
+int pswin_gemm_tn_ring_supported(long long M, int N, int K) {
+    return M >= 64 && M * (long long)(K > N ? K : N) * 2 < 0x7fffffffll && N >= 192 && K >= 192 && N % 192 == 0 && K % 192 == 0;
+}
+
+/* row splits for the ring kernel: one workgroup per CU and launch (256 in all, rounded so that no split is shorter than 4 slabs) */
+int pswin_gemm_tn_ring_splits(long long M, int N, int K, int target_wgs) {
+    if (!pswin_gemm_tn_ring_supported(M, N, K)) return PSWIN_ERR_ARG;
+    const int tiles = (N / 192) * (K / 192);
+    if (target_wgs <= 0) target_wgs = 256;
+    int s = target_wgs / tiles;
+    const int smax = (int)(M / 256) > 0 ? (int)(M / 256) : 1;
+    if (s > smax) s = smax;
+    return s < 1 ? 1 : s;
+}
+
+int pswin_gemm_tn_ring(const void* dy, const void* x, void* partial, int partial_dtype, long long M, int N, int K, int splits, void* stream) {
+    PSWIN_CHECK_ARG(dy && x && partial && pswin_gemm_tn_ring_supported(M, N, K) && splits >= 1 && splits <= M / 64 && valid_dtype(partial_dtype));
+    PSWIN_CHECK_ARG(aligned16(dy) && aligned16(x) && aligned16(partial));
+    if (partial_dtype == PSWIN_BF16) return launch_tn_ring<true>(dy, x, partial, (int)M, N, K, splits, (hipStream_t)stream);
+    return launch_tn_ring<false>(dy, x, partial, (int)M, N, K, splits, (hipStream_t)stream);
 }
 
 int pswin_gemm_tn(const void* dy, const void* x, float* partial, long long M, int N, int K, int splits, void* stream) {

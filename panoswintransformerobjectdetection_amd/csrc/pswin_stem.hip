@@ -358,8 +358,19 @@ __global__ __launch_bounds__(TWG) void stem_conv3_bwd_kernel(const void* __restr
                 }
             }
             if constexpr (APPLY) {
+#if PSWIN_STEM_PACK2 == 2       // probe: every site packed with one conversion per pair EXCEPT this one
+                const u32x4 o = {(unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16), (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16),
+                                 (unsigned)f32_to_bf16_bits(v[4]) | ((unsigned)f32_to_bf16_bits(v[5]) << 16), (unsigned)f32_to_bf16_bits(v[6]) | ((unsigned)f32_to_bf16_bits(v[7]) << 16)};
+#else
                 const u32x4 o = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+#endif
+#if PSWIN_STEM_PACK2 == 3       // probe: wait states between the conversions and the store that reads them
+                asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+#endif
                 if (valid) __builtin_amdgcn_raw_buffer_store_b128(o, ds, voff + 64u * h, soff, 0);
+#if PSWIN_STEM_PACK2 == 4       // probe: wait states between the store and the next writer of its data registers
+                asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+#endif
             }
         }
         if (tap + 1 < 16) {

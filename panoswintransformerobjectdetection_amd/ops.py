@@ -695,6 +695,31 @@ def gemm_tn(dy, x, splits):
     return part
 
 
+# the three-stage ring kernel for weight gradients (pswin_gemm_tn_ring, round 3); PSWIN_GEMM_TN_RING=0: library batched GEMMs (A/B)
+GEMM_TN_RING = os.environ.get("PSWIN_GEMM_TN_RING", "1") != "0"
+# partial slabs of the row splits in bf16 (what the library's batched GEMM writes; half the slab traffic) or f32
+GEMM_TN_RING_BF16 = os.environ.get("PSWIN_GEMM_TN_RING_BF16", "1") != "0"
+GEMM_TN_RING_WGS = int(os.environ.get("PSWIN_GEMM_TN_RING_WGS", "0"))
+
+
+def gemm_tn_ring_splits(M, N, K):
+    """Row splits for pswin_gemm_tn_ring on dy [M, N], x [M, K] (one workgroup per CU and launch), or 0 = not for this shape."""
+    if not GEMM_TN_RING or M < 2048 or not bool(_lib.load().pswin_gemm_tn_ring_supported(M, N, K)):
+        return 0
+    return int(_lib.load().pswin_gemm_tn_ring_splits(M, N, K, GEMM_TN_RING_WGS))
+
+
+def gemm_tn_ring(dy, x, splits, out_dtype=torch.float32):
+    """[splits, N, K] partial sums of dy^T x over `splits` row ranges (dy [M, N], x [M, K] bf16) in f32 or bf16."""
+    dy, x = dy.contiguous(), x.contiguous()
+    M, N = dy.shape
+    K = x.shape[1]
+    part = torch.empty(splits, N, K, dtype=out_dtype, device=x.device)
+    call("pswin_gemm_tn_ring", x, ptr(dy), ptr(x), ptr(part), dtype_code(part), M, N, K, int(splits),
+         algo_bytes=2 * (M * K + M * N) + part.element_size() * splits * N * K, algo_flops=2 * M * K * N)
+    return part
+
+
 def gemm_nt(x2d, w, bias=None, tile_m=0):
     """y = x2d @ w^T (+ bias): x2d [M, K] bf16, w [N, K] bf16, bias f32 [N] or None -> [M, N] bf16."""
     x2d, w = x2d.contiguous(), w.contiguous()
@@ -793,7 +818,10 @@ def linear_backward(x, wb, dy, weight, bias, zero_bias_cols, need_dx, wbt=None):
             with _lib.timed("lib_gemm_dgrad", 2 * (M * K + M * N + N * K), 2 * M * K * N):
                 dx = dy @ wb
     sp = gemm_tn_splits(M, N, K) if dy.dtype == torch.bfloat16 else 0
-    if sp:                                                   # stages 1-3: HIP weight-gradient kernel, f32 partial slabs
+    rs = gemm_tn_ring_splits(M, N, K) if (dy.dtype == torch.bfloat16 and not sp) else 0
+    if rs:                                                   # stages 1-3: the ring-pipelined HIP weight-gradient kernel
+        part, ch, sp = gemm_tn_ring(dy, x, rs, torch.bfloat16 if (GEMM_TN_RING_BF16 and rs > 1) else torch.float32), rs, rs
+    elif sp:                                                 # (opt-in) the two-stage HIP kernel of round 2, f32 partial slabs
         part, ch = gemm_tn(dy, x, sp), sp
     else:
         ch = _pick_split(M, -(-N // 64) * -(-K // 64))
@@ -805,7 +833,7 @@ def linear_backward(x, wb, dy, weight, bias, zero_bias_cols, need_dx, wbt=None):
     if ch > 1:
         dw = sum_rows(part, ch, N * K, out=grad_slot(weight), owners=(weight,)).view(N, K)
     elif sp:
-        dw = part.view(N, K)
+        dw = part.view(N, K).float()
     db = colsum(dy, zero_bias_cols, owners=(bias,)) if bias is not None else None
     return dx, dw, db
 

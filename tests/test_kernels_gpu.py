@@ -786,6 +786,37 @@ def test_gemm_tn_against_torch(ops, M, N, K, splits):
     assert lib.pswin_gemm_tn_supported(M, 576, 192) == 0 and lib.pswin_gemm_tn_supported(M, N + 64, K) == 0
 
 
+@pytest.mark.parametrize("M,N,K,splits", [(19600, 1152, 384, 0), (16384, 384, 1536, 0), (4096, 768, 3072, 7), (5880, 2304, 768, 0),
+                                          (74480, 576, 192, 0), (74480, 192, 192, 0), (333, 192, 192, 3), (64, 192, 192, 1), (130, 384, 192, 2),
+                                          (1000, 384, 384, 15), (4033, 192, 576, 63)])
+@pytest.mark.parametrize("out_bf16", [False, True])
+def test_gemm_tn_ring_against_torch(ops, M, N, K, splits, out_bf16):
+    """pswin_gemm_tn_ring (three-stage LDS ring, counted waits, asm transposed reads; 192 x 192 tiles: every Linear of the model
+    including the stage-1 qkv / proj pair) against an fp32 matmul of the same bf16 operands: ragged M (the last slabs read past M:
+    zeros; splits with fewer than three slabs; splits that start past M), 1 .. 37 slabs per split, f32 and bf16 partial slabs."""
+    from panoswintransformerobjectdetection_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(M + N + K)
+    dy = torch.randn(M, N, device=DEV).to(torch.bfloat16)
+    x = torch.randn(M, K, device=DEV).to(torch.bfloat16)
+    assert lib.pswin_gemm_tn_ring_supported(M, N, K) == 1
+    sp = splits or lib.pswin_gemm_tn_ring_splits(M, N, K, 0)
+    assert 1 <= sp <= max(1, M // 64)
+    part = ops.gemm_tn_ring(dy, x, sp, torch.bfloat16 if out_bf16 else torch.float32)
+    assert part.shape == (sp, N, K)
+    got = part.float().sum(0)
+    ref = dy.float().t() @ x.float()
+    tol = 2e-3 if not out_bf16 else 6e-3                                       # bf16 slabs: one rounding per split of an O(sqrt(rows)) sum
+    assert torch.allclose(got, ref, rtol=tol, atol=tol * float(ref.abs().max())), (got - ref).abs().max()
+    if not out_bf16 and sp > 1:                                                # the splits partition the rows exactly
+        rows = -(-(-(-M // sp)) // 64) * 64
+        for s_ in (0, sp - 1):
+            lo, hi = min(s_ * rows, M), min((s_ + 1) * rows, M)
+            want = dy[lo:hi].float().t() @ x[lo:hi].float()
+            assert torch.allclose(part[s_], want, rtol=2e-3, atol=2e-3 * float(ref.abs().max()))
+    assert lib.pswin_gemm_tn_ring_supported(M, N + 64, K) == 0 and lib.pswin_gemm_tn_ring_supported(M, N, 96) == 0
+
+
 @pytest.mark.parametrize("M,C,tile", [(16384, 384, 128), (4096, 768, 64), (333, 192, 64), (19600, 384, 128)])
 def test_gelu_backward_fused_into_the_fc2_data_gradient(ops, M, C, tile):
     """pswin_gemm_nt_gelu_bwd: (dy . W2) * gelu'(pre + b1) and the per-tile column sums, against fp32 torch on the same bf16

@@ -16,8 +16,8 @@ from bench_gemm_nt import shapes, t
 
 dev = "cuda:0"
 lib = _lib.load()
-tot = {"lib": 0.0, "hip": 0.0, "floor": 0.0}
-print(f"{'':8s} {'M':>6s} {'K':>5s} {'N':>5s} | lib bmm (ch) | hip tn (splits) | floor us | x count")
+tot = {"lib": 0.0, "hip": 0.0, "ring_f32": 0.0, "ring_bf16": 0.0, "floor": 0.0}
+print(f"{'':8s} {'M':>6s} {'K':>5s} {'N':>5s} | lib bmm (ch) | hip tn (splits) | ring f32 / bf16 (splits) | floor us | x count")
 for name, M, K, N, cnt in shapes:
     x = torch.randn(M, K, device=dev).to(torch.bfloat16)
     dy = torch.randn(M, N, device=dev).to(torch.bfloat16)
@@ -35,8 +35,23 @@ for name, M, K, N, cnt in shapes:
                 res.append((s2, round(t(lambda: ops.gemm_tn(dy, x, s2)), 1)))
             print("      sweep (splits, us):", res, flush=True)
     fl = max((2 * (M * K + M * N) + 4 * N * K) / 6.3e12, 2.0 * M * K * N / 2.5e15) * 1e6
-    print(f"{name:8s} {M:6d} {K:5d} {N:5d} | {lt:7.1f} ({ch:3d}) | {ht:7.1f} ({sp:3d})   | {fl:6.1f}   | x{cnt}", flush=True)
+    rf = rb = float("nan")
+    rs = 0
+    if lib.pswin_gemm_tn_ring_supported(M, N, K):
+        rs = lib.pswin_gemm_tn_ring_splits(M, N, K, 0)
+        rf = t(lambda: ops.gemm_tn_ring(dy, x, rs, torch.float32))
+        rb = t(lambda: ops.gemm_tn_ring(dy, x, rs, torch.bfloat16))
+        if "--sweep" in sys.argv:
+            tiles = (N // 192) * (K // 192)
+            res = []
+            for wgs in (128, 192, 256, 384, 512):
+                s2 = max(1, min(M // 64, wgs // tiles))
+                res.append((s2, round(t(lambda: ops.gemm_tn_ring(dy, x, s2, torch.bfloat16)), 1)))
+            print("      ring sweep (splits, us, bf16 slabs):", res, flush=True)
+    print(f"{name:8s} {M:6d} {K:5d} {N:5d} | {lt:7.1f} ({ch:3d}) | {ht:7.1f} ({sp:3d})   | {rf:7.1f} / {rb:7.1f} ({rs:3d}) | {fl:6.1f}   | x{cnt}", flush=True)
     tot["lib"] += lt * cnt
+    tot["ring_f32"] += (rf if rf == rf else lt) * cnt
+    tot["ring_bf16"] += (rb if rb == rb else lt) * cnt
     tot["hip"] += (ht if ht == ht else lt) * cnt
     tot["floor"] += fl * cnt
 print("per step (us):", {k: round(v) for k, v in tot.items()})
