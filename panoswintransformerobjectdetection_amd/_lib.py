@@ -71,6 +71,8 @@ _PROTOTYPES = {
     "pswin_roi_align_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "pswin_gemm_nt_supported": [ctypes.c_longlong, _i, _i],
     "pswin_gemm_nt": [_vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _i, _vp],
+    "pswin_gemm_nt_ring_supported": [ctypes.c_longlong, _i, _i],
+    "pswin_gemm_nt_ring": [_vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _i, _vp],
     "pswin_gemm_nt_gelu_fwd": [_vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _i, _vp],
     "pswin_gemm_nt_partial_rows": [ctypes.c_longlong, _i],
     "pswin_gemm_nt_gelu_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _i, _vp],

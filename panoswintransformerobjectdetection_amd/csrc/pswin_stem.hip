@@ -71,11 +71,11 @@ __device__ inline void swap16_u32(unsigned& a, unsigned& b) {
     b = r[1];
 }
 
-// NOT pack2_bf16 (one v_cvt_pk_bf16_f32 for both values) in this file: with it the stem's weight gradients came out non-finite
-// (tests/test_backbone_gpu.py::test_hipgraph_replay_matches_eager, 256x512 input) -- the operands here often come straight from
-// MFMA accumulators, and the two-source form evidently does not get the wait states the one-value form gets (see the note above).
+// One v_cvt_pk_bf16_f32 per pair (pack2_bf16).  Round 2 kept the two-conversion form here because the short form produced non-finite
+// weight gradients; round 3 found why (it was never the conversion): the store of stem_conv3_bwd_kernel<true> below -- see the comment
+// there.  PSWIN_STEM_PACK2=0 builds the old form (A/B).
 #ifndef PSWIN_STEM_PACK2
-#define PSWIN_STEM_PACK2 0
+#define PSWIN_STEM_PACK2 1
 #endif
 __device__ inline unsigned pack_bf16(float lo, float hi) {
 #if PSWIN_STEM_PACK2
@@ -358,19 +358,14 @@ __global__ __launch_bounds__(TWG) void stem_conv3_bwd_kernel(const void* __restr
                 }
             }
             if constexpr (APPLY) {
-#if PSWIN_STEM_PACK2 == 2       // probe: every site packed with one conversion per pair EXCEPT this one
-                const u32x4 o = {(unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16), (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16),
-                                 (unsigned)f32_to_bf16_bits(v[4]) | ((unsigned)f32_to_bf16_bits(v[5]) << 16), (unsigned)f32_to_bf16_bits(v[6]) | ((unsigned)f32_to_bf16_bits(v[7]) << 16)};
-#else
                 const u32x4 o = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
-#endif
-#if PSWIN_STEM_PACK2 == 3       // probe: wait states between the conversions and the store that reads them
-                asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
-#endif
-                if (valid) __builtin_amdgcn_raw_buffer_store_b128(o, ds, voff + 64u * h, soff, 0);
-#if PSWIN_STEM_PACK2 == 4       // probe: wait states between the store and the next writer of its data registers
-                asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
-#endif
+                // The tap offset rides in the VECTOR offset, not in the scalar one.  hipcc's hazard recognizer pads a 128-bit buffer
+                // store against the next VALU write of its data registers only when the store has NO scalar-register offset (the rule
+                // of the older GCN parts); with `soff` in an SGPR it pads nothing, and the next pixel's arithmetic, which reuses the
+                // four data registers one wait state later, overwrote them before the store had read them -- deterministically wrong
+                // dy2 (f32 bit patterns where bf16 pairs belong) once the packing got short enough (one v_cvt_pk_bf16_f32 per pair) to
+                // put the overwrite that close; DESIGN.md section 5, "the stem's non-finite gradients".
+                if (valid) __builtin_amdgcn_raw_buffer_store_b128(o, ds, voff + 64u * h + (unsigned)soff, 0, 0);
             }
         }
         if (tap + 1 < 16) {

@@ -732,6 +732,28 @@ def gemm_nt(x2d, w, bias=None, tile_m=0):
     return y
 
 
+# the persistent ring-pipelined GEMM (pswin_gemm_nt_ring, round 3) instead of the tile-per-workgroup kernel where both apply;
+# PSWIN_GEMM_NT_RING=0: round 2's kernel (A/B)
+GEMM_NT_RING = os.environ.get("PSWIN_GEMM_NT_RING", "1") != "0"
+GEMM_NT_RING_WGS = int(os.environ.get("PSWIN_GEMM_NT_RING_WGS", "0"))
+
+
+def gemm_nt_ring_ok(M, K, N):
+    return GEMM_NT_RING and M >= 4096 and bool(_lib.load().pswin_gemm_nt_ring_supported(M, K, N))
+
+
+def gemm_nt_ring(x2d, w, bias=None):
+    """y = x2d @ w^T (+ bias) on the persistent ring kernel: x2d [M, K] bf16, w [N, K] bf16, bias f32 [N] or None -> [M, N] bf16."""
+    x2d, w = x2d.contiguous(), w.contiguous()
+    M, K = x2d.shape
+    N = w.shape[0]
+    y = torch.empty(M, N, dtype=torch.bfloat16, device=x2d.device)
+    b = None if bias is None else bias.detach().float().contiguous()
+    call("pswin_gemm_nt_ring", x2d, ptr(x2d), ptr(w), ptr(b), ptr(y), M, K, N, GEMM_NT_RING_WGS,
+         algo_bytes=2 * (M * K + M * N + N * K), algo_flops=2 * M * K * N)
+    return y
+
+
 def skinny_gemm_supported(x2d, n_out):
     """bf16 rows x a small weight: the shapes pswin_gemm_skinny is instantiated for (stage-0 projections, stage-1 proj)"""
     return (x2d.dtype == torch.bfloat16 and x2d.is_cuda and x2d.shape[0] >= 4096

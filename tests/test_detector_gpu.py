@@ -80,6 +80,18 @@ def test_configs2_workload_panoswin_t_512x1024_step_and_its_hipgraph_arrangement
     uses -- backbone forward | heads on detached maps | backbone backward fed with the heads' feature-map gradients -- reproduces
     the end-to-end backbone gradients; (3) that arrangement captured as THREE hipGraphs sharing a memory pool (what the bench
     replays) gives the same losses and backbone gradients as the eager step, first and later replays."""
+    # Everything -- parameter allocation, the eager passes, warm-up, capture, replay -- runs on ONE side stream, as in bench.py: autograd's
+    # AccumulateGrad nodes remember the stream of the first backward pass, and nodes created on the default stream make a later capture
+    # on another stream synchronise with it (torch warns "may break CUDA graph capture"; here hipStreamEndCapture then crashes).
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        _configs2_body(side)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+
+
+def _configs2_body(side):
     from _util import TCFG, ZERO_GRAD_KEYS, record
     from panoswintransformerobjectdetection_amd import ops as _ops
     from panoswintransformerobjectdetection_amd.detector import MiniMaskRCNN, synthetic_targets
@@ -154,7 +166,7 @@ def test_configs2_workload_panoswin_t_512x1024_step_and_its_hipgraph_arrangement
             red.pack_grads()
             return gbuf[0]
 
-        seq = GraphedSequence([phase_fwd, phase_heads, phase_bwd], warmup=2, stream=torch.cuda.Stream())
+        seq = GraphedSequence([phase_fwd, phase_heads, phase_bwd], warmup=2, stream=side)
         for replay in range(3):
             seq.calls[0]()
             seq.calls[1]()

@@ -29,7 +29,8 @@ def _rois(B, H, W, n, seed):
     boxes[2] = torch.tensor([W + 50., 10., W + 80., 40.])                       # outside: every sample beyond x > W
     boxes[3] = torch.tensor([30., 40., 30., 40.])                               # zero area
     boxes[4] = torch.tensor([60., 50., 50., 45.])                               # inverted
-    boxes[5] = torch.tensor([0., 0., float(W), float(H)])                       # the whole image (top level)
+    boxes[5] = torch.tensor([0., 0., float(W), float(H)])                       # the whole image
+    boxes[6] = torch.tensor([-300., -200., 500., 400.])                         # far larger than the image: the coarsest level, mostly outside
     b = torch.randint(0, B, (n, 1), generator=g).float()
     return torch.cat([b, boxes], 1).to(DEV)
 
@@ -65,7 +66,13 @@ def test_roi_align_backward_is_the_adjoint(ops, dtype, P):
     got = [f.grad.float().clone() for f in feats]
     ref_feats = [f.detach().float().requires_grad_(True) for f in feats]
     (_roi_ref.roi_align_fpn(ref_feats, STRIDES, rois, P) * (w.to(dtype).float() if dtype != torch.float32 else w)).sum().backward()
+    used = set(_roi_ref.map_roi_levels(rois, 4).tolist())
+    assert len(used) >= 3
     for l, (g, r) in enumerate(zip(got, ref_feats)):
+        if l not in used:                                                       # a level no RoI maps to: zero gradient, not None
+            assert r.grad is None or float(r.grad.abs().max()) == 0.0
+            assert float(g.abs().max()) == 0.0
+            continue
         scale = float(r.grad.abs().max())
         tol = 1e-4 if dtype == torch.float32 else 1e-2                          # f32 atomics in arrival order; bf16: dout and dfeat rounded once each
         assert g.shape == r.grad.shape and scale > 0

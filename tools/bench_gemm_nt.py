@@ -42,8 +42,8 @@ shapes = [("m1 red", 65536, 384, 192, 1), ("s1 qkv", 74480, 192, 576, 2), ("s1 p
           ("s2 fc1", 16384, 384, 1536, 6), ("s2 fc2", 16384, 1536, 384, 6), ("m3 red", 4096, 1536, 768, 1), ("s3 qkv", 5880, 768, 2304, 2),
           ("s3 proj", 5880, 768, 768, 2), ("s3 fc1", 4096, 768, 3072, 2), ("s3 fc2", 4096, 3072, 768, 2)]
 def main():
-    tot = {"lib_fwd": 0.0, "hip_fwd": 0.0, "lib_dgrad": 0.0, "hip_dgrad": 0.0, "floor": 0.0}
-    print(f"{'':8s} {'M':>6s} {'K':>5s} {'N':>5s} | fwd: lib  hip64 hip128 | dgrad: lib  hip64 hip128 | floor us | x count")
+    tot = {"lib_fwd": 0.0, "hip_fwd": 0.0, "ring_fwd": 0.0, "lib_dgrad": 0.0, "hip_dgrad": 0.0, "ring_dgrad": 0.0, "floor": 0.0}
+    print(f"{'':8s} {'M':>6s} {'K':>5s} {'N':>5s} | fwd: lib  hip64 hip128   ring | dgrad: lib  hip64 hip128   ring | floor us | x count")
     for name, M, K, N, cnt in shapes:
         x = torch.randn(M, K, device=dev).to(torch.bfloat16)
         w = (torch.randn(N, K, device=dev) * 0.05).to(torch.bfloat16)
@@ -54,7 +54,12 @@ def main():
         hf = [t(lambda: ops.gemm_nt(x, w, None, tm)) if ops.gemm_nt_supported(x, N) else float("nan") for tm in (64, 128)]
         hd = [t(lambda: ops.gemm_nt(dy, wt, None, tm)) if ops.gemm_nt_supported(dy, K) else float("nan") for tm in (64, 128)]
         fl = max(2 * (M * K + M * N + N * K) / 6.3e12, 2.0 * M * K * N / 2.5e15) * 1e6
-        print(f"{name:8s} {M:6d} {K:5d} {N:5d} | {lf:8.1f} {hf[0]:6.1f} {hf[1]:6.1f} | {ld:10.1f} {hd[0]:6.1f} {hd[1]:6.1f} | {fl:6.1f}   | x{cnt}", flush=True)
+        lib = ops._lib.load()
+        rf = t(lambda: ops.gemm_nt_ring(x, w)) if lib.pswin_gemm_nt_ring_supported(M, K, N) else float("nan")
+        rd = t(lambda: ops.gemm_nt_ring(dy, wt)) if lib.pswin_gemm_nt_ring_supported(M, N, K) else float("nan")
+        print(f"{name:8s} {M:6d} {K:5d} {N:5d} | {lf:8.1f} {hf[0]:6.1f} {hf[1]:6.1f} {rf:6.1f} | {ld:10.1f} {hd[0]:6.1f} {hd[1]:6.1f} {rd:6.1f} | {fl:6.1f}   | x{cnt}", flush=True)
+        tot["ring_fwd"] += (rf if rf == rf else lf) * cnt
+        tot["ring_dgrad"] += (rd if rd == rd else ld) * cnt
         best = lambda v: min(z for z in v if z == z) if any(z == z for z in v) else float("nan")
         tot["lib_fwd"] += lf * cnt
         tot["lib_dgrad"] += ld * cnt

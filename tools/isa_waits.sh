@@ -7,7 +7,7 @@ set -e
 SRC=$1; PAT=$2; N=${3:-80}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 OUT=/tmp/isa_$$.s
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -I$ROOT/include -I$ROOT/panoswintransformerobjectdetection_amd/csrc -S -o $OUT --cuda-device-only $SRC 2>/dev/null
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -ffp-contract=off -I$ROOT/include -I$ROOT/panoswintransformerobjectdetection_amd/csrc -S -o $OUT --cuda-device-only $SRC 2>/dev/null
 L=$(grep -n "^_Z[A-Za-z0-9_]*$PAT[A-Za-z0-9_]*:" $OUT | head -1 | cut -d: -f1)
 [ -z "$L" ] && { echo "no kernel matching $PAT"; grep -o "^_Z[A-Za-z0-9_]*:" $OUT | head -40; exit 1; }
 sed -n "$L,\$p" $OUT | awk '/s_endpgm/{print; exit} {print}' > $OUT.k

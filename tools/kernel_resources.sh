@@ -3,7 +3,7 @@
 # usage: tools/kernel_resources.sh pswin_attn.hip
 ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 CSRC="$ROOT/panoswintransformerobjectdetection_amd/csrc"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -I"$ROOT/include" -I"$CSRC" \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++20 -fPIC -ffp-contract=off -I"$ROOT/include" -I"$CSRC" \
   -c "$CSRC/$1" -o /tmp/_kr.o -Rpass-analysis=kernel-resource-usage 2>&1 | python3 -c "
 import sys,re
 cur=None
