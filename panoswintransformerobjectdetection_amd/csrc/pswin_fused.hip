@@ -85,6 +85,10 @@ __device__ inline f32x4 mfma(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+#ifdef PSWIN_FUSED_CLOCK_PROBE
+__device__ unsigned long long pswin_fused_clock_probe[256][2];
+#endif
+
 template <bool SAVE>
 __global__ __launch_bounds__(FTHREADS, 2) void win_fused_fwd_kernel(FusedArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -182,6 +186,13 @@ __global__ __launch_bounds__(FTHREADS, 2) void win_fused_fwd_kernel(FusedArgs a)
     }
     __syncthreads();
     int par = 0;
+#ifdef PSWIN_FUSED_CLOCK_PROBE
+    // diagnostic build only (tools/probe/clock_probe.hip): shader-clock ticks and 100 MHz reference ticks around the window loop of
+    // every workgroup -> the clock the chip holds under this kernel's load (MI355X_MICROARCH.md, DVFS give-back item 6).  The stamps
+    // go to a buffer of their own; no output depends on them.
+    const unsigned long long pswin_t0 = __builtin_amdgcn_s_memtime(), pswin_r0 = __builtin_amdgcn_s_memrealtime();
+    __builtin_amdgcn_s_waitcnt(0xC07F);
+#endif
     for (int wb = blockIdx.x; wb < a.nb; wb += gridDim.x, par ^= 1) {
         const char* bcur = bias + par * BIAS_BYTES;
         for (int rep = wave; rep < a.reps; rep += FWAVES) {
@@ -367,6 +378,12 @@ __global__ __launch_bounds__(FTHREADS, 2) void win_fused_fwd_kernel(FusedArgs a)
         }
         __syncthreads();
     }
+#ifdef PSWIN_FUSED_CLOCK_PROBE
+    if (threadIdx.x == 0) {
+        pswin_fused_clock_probe[blockIdx.x][0] = __builtin_amdgcn_s_memtime() - pswin_t0;
+        pswin_fused_clock_probe[blockIdx.x][1] = __builtin_amdgcn_s_memrealtime() - pswin_r0;
+    }
+#endif
 }
 
 // + 15 rows: the padded query rows of the last head read past its 49 rows

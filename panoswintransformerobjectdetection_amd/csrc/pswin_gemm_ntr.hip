@@ -17,6 +17,9 @@
 //     v_permlane16_swap and rows leave as 16-byte stores;
 //   * tiles are dealt so that the workgroups of one XCD (blockIdx % 8 under round-robin placement; speed only) hold consecutive
 //     tiles, column tile fastest: they share activation panels in that XCD's L2.
+#include <type_traits>
+#include <utility>
+
 #include "pswin_common.hpp"
 
 using namespace pswin;
@@ -113,11 +116,61 @@ __global__ __launch_bounds__(R_THREADS, 2) void gemm_nt_ring_kernel(const unsign
     const int d0 = 8 * (g >> 1) + 16 * (g & 1);
     const rsrc_t ys = __builtin_amdgcn_make_buffer_rsrc(Y, 0, (int)((size_t)M * N * 2), 0x00020000);
 
+    // Software pipeline inside a wave: the fragment reads of the NEXT 32-deep half are issued between the MFMAs of the current one
+    // (one read per two MFMAs), so that LDS latency runs under the matrix pipe even when the two waves of a SIMD arrive at the
+    // per-step barrier together.  Step s: [wait slab s | barrier | request slab s + 2]  A: MFMAs (s - 1, second half) + reads (s, first
+    // half)   B: MFMAs (s, first half) + reads (s, second half).  A tile's accumulators are complete after phase A of the step that
+    // follows its last k-step: its epilogue sits there.
+    auto read_half = [&](auto ks_tag, auto n_tag, const char* sa, const char* sb, u32x4 (&af)[R_RT], u32x4 (&bf)[R_CT]) {
+        constexpr int KS = decltype(ks_tag)::value, NN = decltype(n_tag)::value;     // NN 0..8: 3 activation + 6 weight fragments
+        if constexpr (NN < R_RT) af[NN] = *reinterpret_cast<const u32x4*>(sa + NN * 2048 + choff[KS]);
+        else bf[NN - R_RT] = *reinterpret_cast<const u32x4*>(sb + (NN - R_RT) * 2048 + choff[KS]);
+    };
+    auto phase = [&](auto ks_tag, auto read_tag, const char* sa, const char* sb, const u32x4 (&ca)[R_RT], const u32x4 (&cb)[R_CT],
+                     u32x4 (&na)[R_RT], u32x4 (&nb)[R_CT]) {
+        constexpr bool READ = decltype(read_tag)::value;
+        auto slot = [&](auto n_tag) {
+            constexpr int NN = decltype(n_tag)::value, J = NN / R_RT, I = NN % R_RT;     // MFMA NN of 18: acc[I][J]
+            if constexpr (READ && (NN % 2 == 0)) read_half(ks_tag, std::integral_constant<int, NN / 2>{}, sa, sb, na, nb);
+            acc[I][J] = mfma32(cb[J], ca[I], acc[I][J]);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        __builtin_amdgcn_s_setprio(1);
+        [&]<int... Ns>(std::integer_sequence<int, Ns...>) { (slot(std::integral_constant<int, Ns>{}), ...); }(std::make_integer_sequence<int, 18>{});
+        __builtin_amdgcn_s_setprio(0);
+    };
+    auto epilogue = [&](int it_done) {
+        // acc[i][j][e] = Y[row m0 + 48 wm + 16 i + c][column n0 + 96 wn + 16 j + 4 g + e]
+        const int t = it_done * G + slot, tm = t / tiles_n, tn = t - tm * tiles_n;
+        const int m0 = tm * R_BM, n0 = tn * R_BN;
+#pragma unroll
+        for (int i = 0; i < R_RT; ++i) {
+            const unsigned row = (unsigned)(m0 + wm * 48 + 16 * i + c);
+            const unsigned base = row < (unsigned)M ? row * (unsigned)(N * 2) + (unsigned)((n0 + wn * 96 + d0) * 2) : 0xFFFFFF00u;
+#pragma unroll
+            for (int jp = 0; jp < R_CT / 2; ++jp) {
+                f32x4 q0 = acc[i][2 * jp], q1 = acc[i][2 * jp + 1];
+                if (bias) {                             // (an ordinary load here drains the ring once per tile: the biased layers -- qkv --
+                    const float* bp = bias + n0 + wn * 96 + 32 * jp + 4 * g;          //  pay about a step for it)
+                    q0 += *reinterpret_cast<const f32x4*>(bp);
+                    q1 += *reinterpret_cast<const f32x4*>(bp + 16);
+                }
+                const unsigned off = base == 0xFFFFFF00u ? base : base + 64u * jp;
+                __builtin_amdgcn_raw_buffer_store_b128(pack_row8(q0, q1), ys, off, 0, 0);
+                acc[i][2 * jp] = f32x4{0.f, 0.f, 0.f, 0.f};
+                acc[i][2 * jp + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    using KS0 = std::integral_constant<int, 0>;
+    using KS1 = std::integral_constant<int, 1>;
+
     issue_next();
     issue_next();
     const int total = n_my * KT;
-    int stage = 0, kt = 0, it = 0, since_epi = 3;       // since_epi: steps since the last epilogue (its stores are younger than the
-    for (int s = 0; s < total; ++s) {                   // loads of the two steps that follow it)
+    u32x4 a0[R_RT], b0[R_CT], a1[R_RT], b1[R_CT];       // fragments of the first / second 32-deep half
+    int stage = 0, kt = 0, it = 0, since_epi = 3;       // since_epi: steps since the stores of the last epilogue were issued (they are
+    for (int s = 0; s < total; ++s) {                   // younger than the operand loads of the two steps that follow)
         const bool has_next = s + 1 < total, stores_young = since_epi < 2;
         if (has_next) {
             if (stores_young) wait_vm<R_LOADS + R_STORES>();
@@ -126,57 +179,31 @@ __global__ __launch_bounds__(R_THREADS, 2) void gemm_nt_ring_kernel(const unsign
             if (stores_young) wait_vm<R_STORES>();
             else wait_vm<0>();
         }
+        // every read of slab s - 1 has returned (its stage is overwritten by the request below) before any wave passes the barrier
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        issue_next();                                   // slab s + 2, into the stage read during step s - 1
+        issue_next();                                   // slab s + 2
         const char* sa = smem + stage * R_STAGE + a_lane;
         const char* sb = smem + stage * R_STAGE + b_lane;
-        u32x4 af[2][R_RT], bf[2][R_CT];
-#pragma unroll
-        for (int i = 0; i < R_RT; ++i) af[0][i] = *reinterpret_cast<const u32x4*>(sa + i * 2048 + choff[0]);
-#pragma unroll
-        for (int j = 0; j < R_CT; ++j) bf[0][j] = *reinterpret_cast<const u32x4*>(sb + j * 2048 + choff[0]);
-#pragma unroll
-        for (int i = 0; i < R_RT; ++i) af[1][i] = *reinterpret_cast<const u32x4*>(sa + i * 2048 + choff[1]);
-#pragma unroll
-        for (int j = 0; j < R_CT; ++j) bf[1][j] = *reinterpret_cast<const u32x4*>(sb + j * 2048 + choff[1]);
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int j = 0; j < R_CT; ++j)
-#pragma unroll
-                for (int i = 0; i < R_RT; ++i) acc[i][j] = mfma32(bf[ks][j], af[ks][i], acc[i][j]);
-            __builtin_amdgcn_s_setprio(0);
-        }
-        stage = stage == R_STAGES - 1 ? 0 : stage + 1;
         ++since_epi;
-        if (++kt == KT) {
-            // acc[i][j][e] = Y[row m0 + 48 wm + 16 i + c][column n0 + 96 wn + 16 j + 4 g + e]
-            const int t = it * G + slot, tm = t / tiles_n, tn = t - tm * tiles_n;
-            const int m0 = tm * R_BM, n0 = tn * R_BN;
-#pragma unroll
-            for (int i = 0; i < R_RT; ++i) {
-                const unsigned row = (unsigned)(m0 + wm * 48 + 16 * i + c);
-                const unsigned base = row < (unsigned)M ? row * (unsigned)(N * 2) + (unsigned)((n0 + wn * 96 + d0) * 2) : 0xFFFFFF00u;
-#pragma unroll
-                for (int jp = 0; jp < R_CT / 2; ++jp) {
-                    f32x4 q0 = acc[i][2 * jp], q1 = acc[i][2 * jp + 1];
-                    if (bias) {                         // (an ordinary load here drains the ring once per tile: the biased layers -- qkv --
-                        const float* bp = bias + n0 + wn * 96 + 32 * jp + 4 * g;      //  pay ~a step for it; see DESIGN)
-                        q0 += *reinterpret_cast<const f32x4*>(bp);
-                        q1 += *reinterpret_cast<const f32x4*>(bp + 16);
-                    }
-                    const unsigned off = base == 0xFFFFFF00u ? base : base + 64u * jp;
-                    __builtin_amdgcn_raw_buffer_store_b128(pack_row8(q0, q1), ys, off, 0, 0);
-                    acc[i][2 * jp] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    acc[i][2 * jp + 1] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
+        if (s == 0) {
+            [&]<int... Ns>(std::integer_sequence<int, Ns...>) { (read_half(KS0{}, std::integral_constant<int, Ns>{}, sa, sb, a0, b0), ...); }(std::make_integer_sequence<int, 9>{});
+        } else {
+            phase(KS0{}, std::true_type{}, sa, sb, a1, b1, a0, b0);          // MFMAs: second half of slab s - 1 | reads: first half of slab s
+            if (kt == 0) {                              // slab s - 1 closed a tile
+                epilogue(it - 1);
+                since_epi = 0;
             }
+        }
+        phase(KS1{}, std::true_type{}, sa, sb, a0, b0, a1, b1);              // MFMAs: first half of slab s | reads: its second half
+        stage = stage == R_STAGES - 1 ? 0 : stage + 1;
+        if (++kt == KT) {
             kt = 0;
             ++it;
-            since_epi = 0;
         }
     }
+    phase(KS0{}, std::false_type{}, smem, smem, a1, b1, a0, b0);             // the last slab's second half
+    epilogue(n_my - 1);
 }
 
 }  // namespace

@@ -162,7 +162,23 @@ __global__ __launch_bounds__(TN_THREADS, 2) void gemm_tn_kernel(const unsigned s
 // OUT_BF16: the split's partial tile is rounded to bf16 (what the library's batched GEMM writes for its row chunks) -- half the
 // partial-slab traffic of the f32 form, same fixed-order f32 sum of the splits afterwards.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int RING_THREADS = 512, RING_STAGES = 3, RING_PANELS = 6, RING_STAGE_BYTES = RING_PANELS * PANEL;
+constexpr int RING_THREADS = 512;
+// Geometry of one instantiation: the 8 waves form a WK (k) x WN (n) grid of 96 x 48 wave tiles -> macro tile 96 WK x 48 WN, whose
+// columns come from PX = ceil(96 WK / 64) panels of X and PD = ceil(48 WN / 64) panels of dY per 64-row slab.
+//   <2, 4, 3 stages>  192 x 192: every Linear of stages 1-3 (N, K multiples of 192), 48 KB per slab, three slabs in LDS
+//   <1, 8, 2 stages>   96 x 384: stage 0 with K = 96 (qkv N = 288, proj N = 96, fc1 N = 384): the WHOLE gradient in one tile, pure
+//   <4, 2, 2 stages>  384 x  96: stage-0 fc2 (K = 384, N = 96)                              streaming of dY and X, 64 KB per slab
+// A panel whose 64 columns run past the operand's row (K = 96: the second X panel; N = 288 / 96) reads the next row's first columns
+// there -- finite values that only ever meet accumulator columns the epilogue does not store; panels entirely past N re-read the last
+// needed one (cache hits) so that every wave issues the same number of LDS-DMA instructions per slab (the counted waits need that).
+template <int WK, int WN, int STAGES>
+struct RingGeom {
+    static constexpr int PX = (96 * WK + 63) / 64, PD = (48 * WN + 63) / 64, PANELS = PX + PD, STAGE_BYTES = PANELS * PANEL;
+    static constexpr int LOADS = PANELS;                // row blocks per wave and slab: PANELS * 8 blocks over 8 waves
+    static constexpr int XWAVES = PX;                   // waves 0 .. PX-1 bring the X panels (8 blocks = one panel each... see issue)
+    static_assert(WK * WN == 8, "eight waves");
+    static_assert((size_t)STAGES * STAGE_BYTES <= 160 * 1024, "LDS");
+};
 
 // The transposed LDS reads of the ring kernel are inline asm: hipcc (ROCm 7.2) treats the ds_read_tr16 builtin as possibly aliasing
 // every LDS-DMA in flight and puts `s_waitcnt vmcnt(0)` in front of the first read of each step (seen in the ISA with either LDS-DMA
@@ -187,16 +203,18 @@ __device__ inline void wait_frags(Frag (&a)[6], Frag (&b)[3]) {
                  : "memory");
 }
 
-template <bool OUT_BF16>
+template <int WK, int WN, int STAGES, bool OUT_BF16>
 __global__ __launch_bounds__(RING_THREADS, 2) void gemm_tn_ring_kernel(const unsigned short* __restrict__ DY, const unsigned short* __restrict__ X,
                                                                         void* __restrict__ P, int M, int N, int K, int tiles_k, int tiles_n,
                                                                         int rows_per_split) {
+    using G = RingGeom<WK, WN, STAGES>;
     constexpr int IA = 6, JB = 3;                      // 16-wide tiles per wave along k (96 columns) / n (48 columns)
+    constexpr int RING_STAGE_BYTES = G::STAGE_BYTES, LOADS = G::LOADS;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int c = lane & 15, g = lane >> 4;
-    const int wk = wave >> 2, wn = wave & 3;
+    const int wk = wave / WN, wn = wave - wk * WN;
 
     const int ntiles = tiles_k * tiles_n, nwg = gridDim.x;
     int t;
@@ -206,7 +224,7 @@ __global__ __launch_bounds__(RING_THREADS, 2) void gemm_tn_ring_kernel(const uns
     }
     const int split = t / ntiles, tile = t - split * ntiles;
     const int tk = tile / tiles_n, tn = tile - tk * tiles_n;
-    const int k0 = tk * 192, n0 = tn * 192;
+    const int k0 = tk * (96 * WK), n0 = tn * (48 * WN);
     const int m_begin = split * rows_per_split;
     int steps = rows_per_split / MSTEP;
     {
@@ -214,28 +232,33 @@ __global__ __launch_bounds__(RING_THREADS, 2) void gemm_tn_ring_kernel(const uns
         steps = left < steps ? (left > 0 ? left : 0) : steps;
     }
 
-    // LDS-DMA: 48 row blocks (8 rows x 128 B) per slab: waves 0-3 bring the 24 blocks of the three X panels, waves 4-7 those of the
-    // three dY panels, 6 wave instructions each; rows past M read as zeros (buffer range check)
-    const bool mine_x = wave < 4;
+    // LDS-DMA: PANELS x 8 row blocks (8 rows x 128 B) per slab = PANELS blocks per wave: wave w brings blocks w * PANELS .. of the
+    // list [X panels | dY panels]; PANELS is 6 or 8 and PX * 8 a multiple of it, so a wave serves one operand; rows past M read as
+    // zeros (buffer range check)
+    static_assert((G::PX * 8) % LOADS == 0, "a wave's blocks must not straddle the two operands");
+    const bool mine_x = wave * LOADS < G::PX * 8;
     const rsrc_t src = mine_x ? __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(X), 0, (int)((size_t)M * K * 2), 0x00020000)
                               : __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(DY), 0, (int)((size_t)M * N * 2), 0x00020000);
     const unsigned ld2 = (unsigned)((mine_x ? K : N) * 2);
     const int c0 = mine_x ? k0 : n0;
     const int lr = lane >> 3, pch = lane & 7;
-    unsigned goff[6];                                   // byte offset of this lane's 16 bytes, relative to row m of the slab
+    unsigned goff[8];                                   // (LOADS <= 8 used; a dependent array bound captured by the lambdas below made hipcc's host pass drop the kernel stub)
+    const int last_panel = ((mine_x ? K : N) - c0 + 63) / 64 - 1;     // the last panel that holds a column of this operand's tile
 #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-        const int blk_all = (wave & 3) * 6 + j, panel = blk_all >> 3, blk = blk_all & 7;
+    for (int j = 0; j < LOADS; ++j) {
+        const int blk_all = wave * LOADS + j - (mine_x ? 0 : G::PX * 8), blk = blk_all & 7;
+        int panel = blk_all >> 3;
+        panel = panel > last_panel ? (last_panel > 0 ? last_panel : 0) : panel;
         const int row = 8 * blk + lr;
         const int f = ((row >> 1) & 1) | (((row >> 3) & 1) << 1);
         const int col = (((pch >> 1) ^ f) << 4) + ((pch & 1) << 3);
         goff[j] = (unsigned)row * ld2 + (unsigned)((c0 + 64 * panel + col) * 2);
     }
     auto issue = [&](int step, int stage) {
-        char* base = smem + stage * RING_STAGE_BYTES + wave * 6 * 1024;
+        char* base = smem + stage * RING_STAGE_BYTES + wave * LOADS * 1024;
         const unsigned m = (unsigned)(m_begin + step * MSTEP) * ld2;
 #pragma unroll
-        for (int j = 0; j < 6; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(src, (lds_void*)(base + j * 1024), 16, goff[j] + m, 0, 0, 0);
+        for (int j = 0; j < LOADS; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(src, (lds_void*)(base + j * 1024), 16, goff[j] + m, 0, 0, 0);
     };
 
     f32x4 acc[IA][JB];
@@ -265,7 +288,7 @@ __global__ __launch_bounds__(RING_THREADS, 2) void gemm_tn_ring_kernel(const uns
 #pragma unroll
     for (int j = 0; j < JB; ++j) {
         const int col0 = wn * 48 + 16 * j;
-        bbase[j] = xoff[(col0 >> 4) & 3] + (unsigned)((col0 >> 6) * PANEL + 3 * PANEL);
+        bbase[j] = xoff[(col0 >> 4) & 3] + (unsigned)((col0 >> 6) * PANEL + G::PX * PANEL);
     }
     // One MFMA and one transposed read per slot: read n of a set is half (n & 1) of fragment n >> 1 (0..5: k side, 6..8: n side), MFMA
     // n is acc[n % 6][n / 6].  The reads of the NEXT 32-row half are issued between the MFMAs of the current one, so their LDS latency
@@ -306,20 +329,22 @@ __global__ __launch_bounds__(RING_THREADS, 2) void gemm_tn_ring_kernel(const uns
     using KS0 = std::integral_constant<int, 0>;
     using KS1 = std::integral_constant<int, 1>;
 
+    static_assert(STAGES == 2 || STAGES == 3, "");
+    static_assert(STAGES == 2 || LOADS == 6, "the counted wait below is written out for 6 loads per slab");
     if (steps > 0) issue(0, 0);
-    if (steps > 1) issue(1, 1);
+    if (STAGES == 3 && steps > 1) issue(1, 1);
     Frag a0[6], b0[3], a1[6], b1[3];
     int stage = 0;
     for (int st = 0; st < steps; ++st) {
-        // slab st has landed for this wave once at most the 6 younger LDS-DMA instructions (slab st + 1) are outstanding; the barrier
-        // then says so for every wave, and that every wave has the previous slab in registers (the wait on a1 / b1 below), so the stage
-        // the next issue overwrites is free
-        if (st + 1 < steps) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        // slab st has landed for this wave once at most the younger slabs' LDS-DMA instructions (three stages: the 6 of slab st + 1;
+        // two stages: none) are outstanding; the barrier then says so for every wave, and that every wave has the previous slab in
+        // registers (the wait on a1 / b1 below), so the stage the next issue overwrites is free
+        if (STAGES == 3 && st + 1 < steps) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (st > 0) wait_frags(a1, b1);                  // second half of slab st - 1: read during its first half's MFMAs
         __builtin_amdgcn_s_barrier();
         const unsigned stage_off = (unsigned)(stage * RING_STAGE_BYTES);
-        if (st + 2 < steps) issue(st + 2, stage == 0 ? 2 : stage - 1);       // (stage + 2) % 3
+        if (st + STAGES - 1 < steps) issue(st + STAGES - 1, stage == 0 ? STAGES - 1 : stage - 1);       // (stage + STAGES - 1) % STAGES
         if (st == 0) {
             read_all(KS0{}, stage_off, a0, b0);
         } else {
@@ -328,7 +353,7 @@ __global__ __launch_bounds__(RING_THREADS, 2) void gemm_tn_ring_kernel(const uns
         wait_frags(a0, b0);
         __builtin_amdgcn_sched_barrier(0);
         phase(KS1{}, std::true_type{}, stage_off, a0, b0, a1, b1);           // MFMAs of slab st, first half | reads of its second half
-        stage = stage == 2 ? 0 : stage + 1;
+        stage = stage == STAGES - 1 ? 0 : stage + 1;
     }
     if (steps > 0) {
         wait_frags(a1, b1);
@@ -340,9 +365,11 @@ __global__ __launch_bounds__(RING_THREADS, 2) void gemm_tn_ring_kernel(const uns
 #pragma unroll
     for (int j = 0; j < JB; ++j) {
         const int n = n0 + wn * 48 + 16 * j + c;
+        if (n >= N) continue;                           // (tiles wider than the operand: stage 0)
 #pragma unroll
         for (int i = 0; i < IA; ++i) {
             const int k = k0 + wk * 96 + 16 * i + 4 * g;
+            if (k >= K) continue;
             const size_t o = (size_t)split * N * K + (size_t)n * K + k;
             if constexpr (OUT_BF16) {
                 *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(P) + o) = u32x2{pack2_bf16(acc[i][j][0], acc[i][j][1]), pack2_bf16(acc[i][j][2], acc[i][j][3])};
@@ -353,17 +380,26 @@ __global__ __launch_bounds__(RING_THREADS, 2) void gemm_tn_ring_kernel(const uns
     }
 }
 
-template <bool OUT_BF16>
+template <int WK, int WN, int STAGES, bool OUT_BF16>
 int launch_tn_ring(const void* dy, const void* x, void* partial, int M, int N, int K, int splits, hipStream_t st) {
-    constexpr size_t lds = (size_t)RING_STAGES * RING_STAGE_BYTES;
+    using G = RingGeom<WK, WN, STAGES>;
+    constexpr size_t lds = (size_t)STAGES * G::STAGE_BYTES;
     static std::atomic<unsigned long long> configured{0};
-    if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&gemm_tn_ring_kernel<OUT_BF16>), lds, configured)) return rc;
-    const int tiles_k = K / 192, tiles_n = N / 192;
+    if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&gemm_tn_ring_kernel<WK, WN, STAGES, OUT_BF16>), lds, configured)) return rc;
+    const int tiles_k = (K + 96 * WK - 1) / (96 * WK), tiles_n = (N + 48 * WN - 1) / (48 * WN);
     const int rows_per_split = ((M + splits - 1) / splits + MSTEP - 1) / MSTEP * MSTEP;
-    hipLaunchKernelGGL((gemm_tn_ring_kernel<OUT_BF16>), dim3(tiles_k * tiles_n * splits), dim3(RING_THREADS), lds, st,
+    hipLaunchKernelGGL((gemm_tn_ring_kernel<WK, WN, STAGES, OUT_BF16>), dim3(tiles_k * tiles_n * splits), dim3(RING_THREADS), lds, st,
                        reinterpret_cast<const unsigned short*>(dy), reinterpret_cast<const unsigned short*>(x), partial, M, N, K, tiles_k, tiles_n,
                        rows_per_split);
     PSWIN_LAUNCH_RET();
+}
+
+// geometry for a shape: 0 = <2, 4> (192 x 192 tiles), 1 = <1, 8> (K = 96, N <= 384), 2 = <4, 2> (K = 384, N = 96), -1 = none
+inline int ring_geom(int N, int K) {
+    if (N >= 192 && K >= 192 && N % 192 == 0 && K % 192 == 0) return 0;
+    if (K == 96 && N >= 48 && N <= 384 && N % 16 == 0) return 1;
+    if (K == 384 && N == 96) return 2;
+    return -1;
 }
 
 template <int PA, int PB>
@@ -407,13 +443,14 @@ int pswin_gemm_tn_splits(long long M, int N, int K) {
 }
 
 int pswin_gemm_tn_ring_supported(long long M, int N, int K) {
-    return M >= 64 && M * (long long)(K > N ? K : N) * 2 < 0x7fffffffll && N >= 192 && K >= 192 && N % 192 == 0 && K % 192 == 0;
+    return M >= 64 && (M + 64) * (long long)(K > N ? K : N) * 2 < 0xFFFFFF00ll && ring_geom(N, K) >= 0;
 }
 
 /* row splits for the ring kernel: one workgroup per CU and launch (256 in all, rounded so that no split is shorter than 4 slabs) */
 int pswin_gemm_tn_ring_splits(long long M, int N, int K, int target_wgs) {
     if (!pswin_gemm_tn_ring_supported(M, N, K)) return PSWIN_ERR_ARG;
-    const int tiles = (N / 192) * (K / 192);
+    const int geom = ring_geom(N, K);
+    const int tiles = geom == 0 ? (N / 192) * (K / 192) : 1;
     if (target_wgs <= 0) target_wgs = 256;
     int s = target_wgs / tiles;
     const int smax = (int)(M / 256) > 0 ? (int)(M / 256) : 1;
@@ -424,8 +461,14 @@ int pswin_gemm_tn_ring_splits(long long M, int N, int K, int target_wgs) {
 int pswin_gemm_tn_ring(const void* dy, const void* x, void* partial, int partial_dtype, long long M, int N, int K, int splits, void* stream) {
     PSWIN_CHECK_ARG(dy && x && partial && pswin_gemm_tn_ring_supported(M, N, K) && splits >= 1 && splits <= M / 64 && valid_dtype(partial_dtype));
     PSWIN_CHECK_ARG(aligned16(dy) && aligned16(x) && aligned16(partial));
-    if (partial_dtype == PSWIN_BF16) return launch_tn_ring<true>(dy, x, partial, (int)M, N, K, splits, (hipStream_t)stream);
-    return launch_tn_ring<false>(dy, x, partial, (int)M, N, K, splits, (hipStream_t)stream);
+    const bool bf = partial_dtype == PSWIN_BF16;
+    const hipStream_t st = (hipStream_t)stream;
+    switch (ring_geom(N, K)) {
+        case 0: return bf ? launch_tn_ring<2, 4, 3, true>(dy, x, partial, (int)M, N, K, splits, st) : launch_tn_ring<2, 4, 3, false>(dy, x, partial, (int)M, N, K, splits, st);
+        case 1: return bf ? launch_tn_ring<1, 8, 2, true>(dy, x, partial, (int)M, N, K, splits, st) : launch_tn_ring<1, 8, 2, false>(dy, x, partial, (int)M, N, K, splits, st);
+        case 2: return bf ? launch_tn_ring<4, 2, 2, true>(dy, x, partial, (int)M, N, K, splits, st) : launch_tn_ring<4, 2, 2, false>(dy, x, partial, (int)M, N, K, splits, st);
+        default: return PSWIN_ERR_UNSUPPORTED;
+    }
 }
 
 int pswin_gemm_tn(const void* dy, const void* x, float* partial, long long M, int N, int K, int splits, void* stream) {

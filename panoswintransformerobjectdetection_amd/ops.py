@@ -906,12 +906,18 @@ class _Fc1Gelu(torch.autograd.Function):
              algo_bytes=2 * M * (K + 2 * N))
         db = sum_rows(ws, lib.pswin_fc1_gelu_partial_rows(M), N, owners=(ctx.bias,))
         dx = skinny_gemm(dy, wb, None, transpose_w=True) if ctx.needs_input_grad[0] else None
-        ch = _pick_split(M, -(-N // 64) * -(-K // 64))
-        with _lib.timed("lib_gemm_wgrad", 2 * (M * K + M * N) + 4 * N * K, 2 * M * K * N):
-            if ch > 1:
-                part = torch.bmm(dy.view(ch, M // ch, N).transpose(1, 2), x.view(ch, M // ch, K))
-            else:
-                dw = (dy.t() @ x).float()
+        rs = gemm_tn_ring_splits(M, N, K)
+        if rs:                                                   # the ring kernel's stage-0 geometry: the whole [N, K] gradient per workgroup
+            part, ch = gemm_tn_ring(dy, x, rs, torch.bfloat16 if (GEMM_TN_RING_BF16 and rs > 1) else torch.float32), rs
+            if ch == 1:
+                dw = part.view(N, K).float()
+        else:
+            ch = _pick_split(M, -(-N // 64) * -(-K // 64))
+            with _lib.timed("lib_gemm_wgrad", 2 * (M * K + M * N) + 4 * N * K, 2 * M * K * N):
+                if ch > 1:
+                    part = torch.bmm(dy.view(ch, M // ch, N).transpose(1, 2), x.view(ch, M // ch, K))
+                else:
+                    dw = (dy.t() @ x).float()
         if ch > 1:
             dw = sum_rows(part, ch, N * K, out=grad_slot(ctx.weight), owners=(ctx.weight,)).view(N, K)
         return dx, dw, db, None

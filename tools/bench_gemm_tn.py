@@ -18,6 +18,7 @@ dev = "cuda:0"
 lib = _lib.load()
 tot = {"lib": 0.0, "hip": 0.0, "ring_f32": 0.0, "ring_bf16": 0.0, "floor": 0.0}
 print(f"{'':8s} {'M':>6s} {'K':>5s} {'N':>5s} | lib bmm (ch) | hip tn (splits) | ring f32 / bf16 (splits) | floor us | x count")
+shapes = [("s0 qkv", 275576, 96, 288, 2), ("s0 proj", 275576, 96, 96, 2), ("s0 fc1", 262144, 96, 384, 2), ("s0 fc2", 262144, 384, 96, 2)] + list(shapes)
 for name, M, K, N, cnt in shapes:
     x = torch.randn(M, K, device=dev).to(torch.bfloat16)
     dy = torch.randn(M, N, device=dev).to(torch.bfloat16)
@@ -42,7 +43,7 @@ for name, M, K, N, cnt in shapes:
         rf = t(lambda: ops.gemm_tn_ring(dy, x, rs, torch.float32))
         rb = t(lambda: ops.gemm_tn_ring(dy, x, rs, torch.bfloat16))
         if "--sweep" in sys.argv:
-            tiles = (N // 192) * (K // 192)
+            tiles = (N // 192) * (K // 192) if K % 192 == 0 and N % 192 == 0 else 1
             res = []
             for wgs in (128, 192, 256, 384, 512):
                 s2 = max(1, min(M // 64, wgs // tiles))
