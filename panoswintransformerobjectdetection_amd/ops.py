@@ -704,7 +704,7 @@ GEMM_TN_RING_WGS = int(os.environ.get("PSWIN_GEMM_TN_RING_WGS", "0"))
 
 def gemm_tn_ring_splits(M, N, K):
     """Row splits for pswin_gemm_tn_ring on dy [M, N], x [M, K] (one workgroup per CU and launch), or 0 = not for this shape."""
-    if not GEMM_TN_RING or M < 2048 or not bool(_lib.load().pswin_gemm_tn_ring_supported(M, N, K)):
+    if not GEMM_TN_RING or M < 512 or not bool(_lib.load().pswin_gemm_tn_ring_supported(M, N, K)):
         return 0
     return int(_lib.load().pswin_gemm_tn_ring_splits(M, N, K, GEMM_TN_RING_WGS))
 
@@ -732,9 +732,10 @@ def gemm_nt(x2d, w, bias=None, tile_m=0):
     return y
 
 
-# the persistent ring-pipelined GEMM (pswin_gemm_nt_ring, round 3) instead of the tile-per-workgroup kernel where both apply;
-# PSWIN_GEMM_NT_RING=0: round 2's kernel (A/B)
-GEMM_NT_RING = os.environ.get("PSWIN_GEMM_NT_RING", "1") != "0"
+# the persistent ring-pipelined GEMM (pswin_gemm_nt_ring, round 3) instead of the tile-per-workgroup kernel.  Measured and NOT adopted
+# (profiles/r03_gemm_nt_ring_vs_tiled.txt: 1073 vs 950 us per step for the forward pool, 1046 vs 946 for the data gradients; it wins on
+# 5 of 30 shapes by 1-4 us): kept for the record and for A/B (PSWIN_GEMM_NT_RING=1), parity-tested, off by default
+GEMM_NT_RING = os.environ.get("PSWIN_GEMM_NT_RING", "0") != "0"
 GEMM_NT_RING_WGS = int(os.environ.get("PSWIN_GEMM_NT_RING_WGS", "0"))
 
 
