@@ -502,6 +502,16 @@ int pswin_win_attn_fused_fwd(const void* x, const void* w_qkv, const float* b_qk
                              void* qkv_out, void* att_out, float* lse_out, long long n_windows, int n_bias_windows, int C,
                              int heads, float scale, int dtype, void* stream);
 
+/* The same fusion WITHOUT the proj Linear for the stages behind the first one (csrc/pswin_qkvattn.hip, round 3): qkv Linear (HOT:287) +
+ * attention core (HOT:288-308) of one (window, head) per wave, C = 192 (6 heads) or 384 (12); the head's 96 weight rows stay in LDS for
+ * the lifetime of a workgroup.  y: attention output rows [n_windows * 49, C] (the input of the proj GEMM).  qkv_out / lse_out: both or
+ * neither (training): q, k, v as packed [n][heads][3][49][32] blocks and the log-sum-exp rows [n][heads][64], what pswin_attn_bwd_ex
+ * (ld_in 32, win_stride heads * 3 * 49 * 32, head_stride 3 * 49 * 32) reads.  Other arguments as pswin_win_attn_fused_fwd. */
+int pswin_qkv_attn_fused_supported(int C, int heads, int dtype);
+int pswin_qkv_attn_fused_fwd(const void* x, const void* w_qkv, const float* b_qkv, const float* dist_tiles, int n_dist, const float* alpha,
+                             const float* beta, const float* mask_tiles, int n_mask, void* y, void* qkv_out, float* lse_out, long long n_windows,
+                             int n_bias_windows, int C, int heads, float scale, int dtype, void* stream);
+
 /* Gradients of pswin_attn_fwd.  dq, dk, dv use the q/k/v addressing (ld_dqkv), dout the out addressing.
  * dist_tiles_t / mask_tiles_t: the TRANSPOSED tiles.  n_chunks splits the batch loop (1 <= n_chunks <=
  * n_windows / n_bias_windows, must divide it).

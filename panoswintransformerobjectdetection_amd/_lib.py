@@ -102,6 +102,8 @@ _PROTOTYPES = {
     "pswin_win_attn_fused_supported": [_i, _i, _i],
     "pswin_win_attn_fused_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _i,
                                  _f, _i, _vp],
+    "pswin_qkv_attn_fused_supported": [_i, _i, _i],
+    "pswin_qkv_attn_fused_fwd": [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _i, _f, _i, _vp],
     "pswin_attn_suggest_chunks": [_i, _i, _i, _i],
     "pswin_attn_bwd": [_vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp,
                        _i, _i, _i, _i, _f, _i, _vp],

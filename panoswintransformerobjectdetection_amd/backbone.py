@@ -162,6 +162,10 @@ class PanoSwinTransformerBlock(nn.Module, DoubleModeModule):
         if fuse and ops.FUSED_WINDOW_ATTENTION and ops.window_attention_fused_supported(win.view(-1, C), a.num_heads):
             # C = 96: qkv Linear, attention and proj Linear of a window in one kernel, weights resident in LDS
             att = ops.window_attention_fused(win.view(-1, C), a, dist, mask, nW).view(B, nW * WTOK, C)
+        elif fuse and ops.window_attention_qkv_fused_supported(win.view(-1, C), a.num_heads):
+            # C = 192 / 384: qkv Linear + attention core of a (window, head) in one kernel (the head's weight rows resident in LDS)
+            att = ops.window_attention_qkv_fused(win.view(-1, C), a, dist, mask, nW)
+            att = _linear(att, a.proj, cd, use_bias=False).view(B, nW * WTOK, C)
         else:
             qkv = _linear(win.view(-1, C), a.qkv, cd, zero_bias_cols=(C, 2 * C))      # [B*nW*49, 3C]
             att = ops.window_attention(qkv, a.sphere_position_alpha_table_Te, a.sphere_position_beta_table_Te, dist, mask,

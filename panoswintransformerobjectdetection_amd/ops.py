@@ -725,6 +725,8 @@ def gemm_nt(x2d, w, bias=None, tile_m=0):
     x2d, w = x2d.contiguous(), w.contiguous()
     M, K = x2d.shape
     N = w.shape[0]
+    if gemm_nt_ring_ok(M, K, N):                    # (opt-in A/B, see GEMM_NT_RING)
+        return gemm_nt_ring(x2d, w, bias)
     y = torch.empty(M, N, dtype=torch.bfloat16, device=x2d.device)
     b = None if bias is None else bias.detach().float().contiguous()
     call("pswin_gemm_nt", x2d, ptr(x2d), ptr(w), ptr(b), ptr(y), M, K, N, int(tile_m),
@@ -1427,3 +1429,70 @@ def roi_align_fpn(feats, strides, rois, out_size, sampling_ratio=0, aligned=True
     if roi_level is None:
         roi_level = map_roi_levels(rois, len(feats), finest_scale)
     return _RoiAlignFPN.apply(rois, roi_level, int(out_size), sampling_ratio, aligned, tuple(strides), *feats)
+
+
+# ------------------------------------------------------------------------------------------------
+# qkv Linear + attention core in one kernel for C = 192 / 384 (pswin_qkv_attn_fused_fwd, round 3)
+# ------------------------------------------------------------------------------------------------
+# PSWIN_FUSED_QKV_ATTN=0: the unfused chain qkv GEMM -> pswin_attn_fwd (A/B)
+FUSED_QKV_ATTENTION = os.environ.get("PSWIN_FUSED_QKV_ATTN", "1") != "0"
+
+
+class _WindowAttentionQkvFused(torch.autograd.Function):
+    """self.qkv(x) and the attention core of WindowAttention.forward (HOT:287-308) as ONE kernel per (window, head) wave; the proj
+    Linear stays with the caller.  Training mode stores q, k, v (packed [n, heads, 3, 49, 32]) and the log-sum-exp rows; the backward
+    pass is the unfused one on them (pswin_attn_bwd_ex, then the qkv weight / data gradients): identical kernels and summation order
+    to the unfused path."""
+
+    @staticmethod
+    def forward(ctx, x, w_qkv, b_qkv, alpha, beta, dist, mask, heads, scale, n_bias_windows, wq_lp, wq_lp_t, grad_mode):
+        x = x.contiguous()
+        rows, C = x.shape
+        n = rows // WTOK
+        assert rows % WTOK == 0 and C == heads * _lib.HEAD_DIM
+        wq = (wq_lp if wq_lp is not None else w_qkv.to(x.dtype)).contiguous()
+        bq = None if b_qkv is None else b_qkv.detach().float().contiguous()
+        alpha_c = alpha.detach().contiguous() if dist is not None else None
+        beta_c = beta.detach().contiguous()
+        save = grad_mode and any(ctx.needs_input_grad)
+        y = torch.empty_like(x)
+        qkv = lse = None
+        if save:
+            qkv = torch.empty(n, heads, 3, WTOK, _lib.HEAD_DIM, dtype=x.dtype, device=x.device)
+            lse = torch.empty(n, heads, WPAD, dtype=torch.float32, device=x.device)
+        flops = n * (2 * WTOK * C * 3 * C + heads * 4 * WTOK * WTOK * _lib.HEAD_DIM)
+        call("pswin_qkv_attn_fused_fwd", x, ptr(x), ptr(wq), ptr(bq), ptr(None if dist is None else dist.fwd), 0 if dist is None else dist.n,
+             ptr(alpha_c), ptr(beta_c), ptr(None if mask is None else mask.fwd), 0 if mask is None else mask.n, ptr(y), ptr(qkv), ptr(lse), n,
+             n_bias_windows, C, heads, float(scale), dtype_code(x), algo_bytes=rows * C * 2 * (5 if save else 2), algo_flops=flops)
+        if save:
+            ctx.save_for_backward(x, qkv, lse, wq, alpha_c, beta_c, wq_lp_t)
+            ctx.params = (w_qkv, b_qkv, alpha if dist is not None else None, beta)
+            ctx.cfg = (dist, mask, heads, float(scale), n_bias_windows)
+        return y
+
+    @staticmethod
+    def backward(ctx, datt):
+        x, qkv, lse, wq, alpha_c, beta_c, wq_t = ctx.saved_tensors
+        w_qkv, b_qkv, alpha, beta = ctx.params
+        dist, mask, heads, scale, nb = ctx.cfg
+        C = x.shape[1]
+        dqkv, _, _, dalpha, dbeta = attention_backward(qkv, None, None, lse, alpha_c, beta_c, dist, mask, datt, heads, scale, nb, None,
+                                                        ctx.needs_input_grad[3] or ctx.needs_input_grad[4], (alpha, beta), packed=True)
+        # the K third of d(qkv) sums to zero over every window (rows of dS sum to 0): its bias gradient is not summed
+        dx, dwq, dbq = linear_backward(x, wq, dqkv, w_qkv, b_qkv, (C, 2 * C), ctx.needs_input_grad[0], wq_t)
+        return dx, dwq, dbq, dalpha, dbeta, None, None, None, None, None, None, None, None
+
+
+def window_attention_qkv_fused_supported(x2d, heads):
+    return (FUSED_QKV_ATTENTION and x2d.is_cuda and x2d.dim() == 2 and x2d.dtype == torch.bfloat16
+            and bool(_lib.load().pswin_qkv_attn_fused_supported(x2d.shape[1], heads, BF16)))
+
+
+def window_attention_qkv_fused(x2d, attn, dist, mask, n_bias_windows):
+    """attention(qkv(x2d)) -- everything of WindowAttention.forward in front of self.proj -- for window rows x2d [n*49, C] and the
+    parameter holder `attn`: see _WindowAttentionQkvFused."""
+    lq = attn.qkv.__dict__.get("_lowp")
+    return _WindowAttentionQkvFused.apply(x2d, attn.qkv.weight, attn.qkv.bias, attn.sphere_position_alpha_table_Te,
+                                          attn.sphere_position_beta_table_Te, _as_tiles(dist), _as_tiles(mask), attn.num_heads, attn.scale,
+                                          n_bias_windows, lq[0] if lq is not None else None, attn.qkv.__dict__.get("_lowp_t"),
+                                          torch.is_grad_enabled())

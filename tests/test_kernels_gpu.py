@@ -607,16 +607,17 @@ def test_window_attention_module_against_the_reference_capture(ops, name, pano, 
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
 
 
-# ---- the per-window fused qkv -> attention -> proj kernel (csrc/pswin_fused.hip, C = 96 / 3 heads, bf16) ------------------
-def _fused_case(B, nW, pano, mask_kind, seed):
+# ---- the per-window fused kernels: qkv -> attention -> proj (csrc/pswin_fused.hip, C = 96 / 3 heads) and qkv -> attention
+# (csrc/pswin_qkvattn.hip, C = 192 / 384), bf16 ------------------------------------------------------------------------------
+def _fused_case(B, nW, pano, mask_kind, seed, C=96):
     from detfill import det_fill_module
-    att = po.WindowAttention(96, 7, 3)
+    att = po.WindowAttention(C, 7, C // 32)
     det_fill_module(att, f"fz:{seed}")
     with torch.no_grad():                       # the kernel's operands are bf16: the oracle sees the same rounded weights
         for lin in (att.qkv, att.proj):
             lin.weight.copy_(lin.weight.to(torch.bfloat16).float())
     n = B * nW
-    x = det_uniform((n, 49, 96), f"fz:{seed}:x", 1.0).to(torch.bfloat16).float()
+    x = det_uniform((n, 49, C), f"fz:{seed}:x", 1.0).to(torch.bfloat16).float()
     uv = torch.stack([det_uniform((nW, 49), f"fz:{seed}:u", math.pi), det_uniform((nW, 49), f"fz:{seed}:v", math.pi / 2)], -1)
     uv[0, 44:] = 0.0                            # zero-uv padding slots
     mask = None
@@ -624,30 +625,34 @@ def _fused_case(B, nW, pano, mask_kind, seed):
         mask = torch.where(det_uniform((nW, 49, 49), f"fz:{seed}:m") > 0.4, torch.tensor(-100.0), torch.tensor(0.0))
     elif mask_kind == 4:
         mask = torch.where(det_uniform((B, nW, 49, 49), f"fz:{seed}:m4") > 0.4, torch.tensor(-100.0), torch.tensor(0.0))
-    gout = det_uniform((n, 49, 96), f"fz:{seed}:g", 1.0).to(torch.bfloat16).float()
+    gout = det_uniform((n, 49, C), f"fz:{seed}:g", 1.0).to(torch.bfloat16).float()
     return att, x, uv, mask, gout
 
 
-def _fused_run(ops, att_cpu, x, uv, mask, gout, B, nW, pano, mask_kind, fused):
-    """The product's WindowAttention chain on the GPU in bf16: the fused kernel or the three-kernel chain."""
-    import copy
+def _fused_run(ops, att_cpu, x, uv, mask, gout, B, nW, pano, mask_kind, fused, C=96):
+    """The product's WindowAttention chain on the GPU in bf16: the fused kernel (C = 96: with the proj Linear; C = 192 / 384: qkv +
+    attention core, then the proj GEMM) or the three-kernel chain."""
     from panoswintransformerobjectdetection_amd.backbone import WindowAttention, _linear
-    att = WindowAttention(96, 7, 3)
+    heads = C // 32
+    att = WindowAttention(C, 7, heads)
     att.load_state_dict(att_cpu.state_dict())
     att = att.to(DEV)
-    xd = x.to(DEV).to(torch.bfloat16).view(-1, 96).requires_grad_(True)
+    xd = x.to(DEV).to(torch.bfloat16).view(-1, C).requires_grad_(True)
     uvd = uv.to(DEV)
     dist = ops.Tiles(ops.haversine_windows(uvd, uvd), symmetric=True) if pano else None
     mt = None if mask is None else ops.Tiles(mask.reshape(-1, 49, 49).to(DEV))
     nb = B * nW if mask_kind == 4 else nW
-    if fused:
+    if fused and C == 96:
         y = ops.window_attention_fused(xd, att, dist, mt, nb)
+    elif fused:
+        assert ops.window_attention_qkv_fused_supported(xd, heads)
+        y = _linear(ops.window_attention_qkv_fused(xd, att, dist, mt, nb), att.proj, torch.bfloat16, use_bias=False)
     else:
         qkv = _linear(xd, att.qkv, torch.bfloat16)
-        o = ops.window_attention(qkv, att.sphere_position_alpha_table_Te, att.sphere_position_beta_table_Te, dist, mt, 3,
+        o = ops.window_attention(qkv, att.sphere_position_alpha_table_Te, att.sphere_position_beta_table_Te, dist, mt, heads,
                                  att.scale, nb)
         y = _linear(o, att.proj, torch.bfloat16, use_bias=False)
-    y.backward(gout.to(DEV).to(torch.bfloat16).view(-1, 96))
+    y.backward(gout.to(DEV).to(torch.bfloat16).view(-1, C))
     grads = {k: p.grad.detach().float().cpu() for k, p in att.named_parameters() if p.grad is not None}
     return y.detach().float().cpu(), xd.grad.float().cpu(), grads
 
@@ -703,6 +708,60 @@ def test_fused_window_attention_equals_the_three_kernel_chain(ops, B, nW, pano, 
         yi = ops.window_attention_fused(x.to(DEV).to(torch.bfloat16).view(-1, 96), attd, dist, mt,
                                         B * nW if mask_kind == 4 else nW).float().cpu()
     assert torch.allclose(yi, y1, rtol=1e-2, atol=4e-3 * y1.abs().max().item())
+
+
+QKV_FUSED_CASES = [(192, 2, 3, True, 0), (192, 1, 5, False, 0), (192, 3, 4, False, 3), (192, 2, 3, False, 4), (192, 9, 2, True, 0),
+                   (192, 8, 50, True, 0), (384, 2, 3, True, 0), (384, 2, 3, False, 3), (384, 8, 25, True, 0), (384, 1, 1, True, 0)]
+
+
+@pytest.mark.parametrize("C,B,nW,pano,mask_kind", QKV_FUSED_CASES)
+def test_fused_qkv_attention_against_the_oracle_and_the_chain(ops, C, B, nW, pano, mask_kind):
+    """pswin_qkv_attn_fused_fwd (qkv Linear + attention core of one (window, head) per wave, C = 192 / 384) + the proj GEMM: the output
+    and every gradient against the CPU oracle module on the same bf16-rounded weights / inputs (the bf16 attention tests' tolerance),
+    and against the unfused chain qkv GEMM -> pswin_attn_fwd -> proj GEMM (same rounding points: a few bf16 ulps); the forward-only
+    mode (nothing saved) returns the training mode's output bit for bit (same arithmetic, two more stores)."""
+    att, x, uv, mask, gout = _fused_case(B, nW, pano, mask_kind, f"q{C}{B}{nW}{pano}{mask_kind}", C)
+    xo = x.clone().requires_grad_(True)
+    yo = att(xo, uv.repeat(B, 1, 1), mask, pano) - att.proj.bias
+    (yo * gout).sum().backward()
+    y1, dx1, g1 = _fused_run(ops, att, x, uv, mask, gout, B, nW, pano, mask_kind, True, C)
+    ys, gs = yo.abs().max().item(), xo.grad.abs().max().item()
+    assert torch.allclose(y1.view_as(yo), yo.detach(), rtol=3e-2, atol=2e-2 * ys), (y1.view_as(yo) - yo).abs().max()
+    assert torch.allclose(dx1.view_as(xo.grad), xo.grad, rtol=5e-2, atol=3e-2 * gs)
+    for k, p in att.named_parameters():
+        if k == "proj.bias" or (k.endswith("alpha_table_Te") and not pano):
+            continue
+        assert k in g1, k
+        assert torch.allclose(g1[k], p.grad, rtol=5e-2, atol=3e-2 * p.grad.abs().max().item()), (k, (g1[k] - p.grad).abs().max())
+    y0, dx0, g0 = _fused_run(ops, att, x, uv, mask, gout, B, nW, pano, mask_kind, False, C)
+    assert torch.allclose(y1, y0, rtol=2e-2, atol=1e-2 * y0.abs().max().item())
+    assert torch.allclose(dx1, dx0, rtol=2e-2, atol=1e-2 * dx0.abs().max().item())
+    assert g1.keys() == g0.keys()
+    for k in g0:
+        assert torch.allclose(g1[k], g0[k], rtol=2e-2, atol=1e-2 * g0[k].abs().max().item()), k
+    # inference mode: the attention rows in front of proj
+    from panoswintransformerobjectdetection_amd.backbone import WindowAttention
+    attd = WindowAttention(C, 7, C // 32)
+    attd.load_state_dict(att.state_dict())
+    attd = attd.to(DEV)
+    uvd = uv.to(DEV)
+    dist = ops.Tiles(ops.haversine_windows(uvd, uvd), symmetric=True) if pano else None
+    mt = None if mask is None else ops.Tiles(mask.reshape(-1, 49, 49).to(DEV))
+    xd = x.to(DEV).to(torch.bfloat16).view(-1, C)
+    nb = B * nW if mask_kind == 4 else nW
+    with torch.no_grad():
+        oi = ops.window_attention_qkv_fused(xd, attd, dist, mt, nb)
+    ot = ops.window_attention_qkv_fused(xd.clone().requires_grad_(True), attd, dist, mt, nb)
+    assert torch.equal(oi, ot.detach())
+
+
+def test_fused_qkv_attention_rejects_what_it_is_not_built_for(ops):
+    from panoswintransformerobjectdetection_amd import _lib
+    lib = _lib.load()
+    assert lib.pswin_qkv_attn_fused_supported(192, 6, _lib.BF16) == 1 and lib.pswin_qkv_attn_fused_supported(384, 12, _lib.BF16) == 1
+    assert lib.pswin_qkv_attn_fused_supported(96, 3, _lib.BF16) == 0 and lib.pswin_qkv_attn_fused_supported(768, 24, _lib.BF16) == 0
+    assert lib.pswin_qkv_attn_fused_supported(192, 3, _lib.BF16) == 0 and lib.pswin_qkv_attn_fused_supported(192, 6, _lib.F32) == 0
+    assert not ops.window_attention_qkv_fused_supported(torch.zeros(49, 96, dtype=torch.bfloat16, device=DEV), 3)
 
 
 def test_fused_window_attention_rejects_what_it_is_not_built_for(ops):
