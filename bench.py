@@ -67,14 +67,14 @@ TCFG = dict(embed_dim=96, depths=[2, 2, 6, 2], num_heads=[3, 6, 12, 24], window_
             drop_path_rate=0.2, pano_mode=True)
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md; ~6.3 TB/s achievable)
 MFMA_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak (MI355X_MICROARCH.md)
-TIMED = ("pswin_win_attn_fused_fwd", "pswin_attn_fwd", "pswin_attn_bwd", "pswin_attn_bwd_ex", "pswin_window_gather", "pswin_window_scatter_add",
+TIMED = ("pswin_win_attn_fused_fwd", "pswin_qkv_attn_fused_fwd", "pswin_attn_fwd", "pswin_attn_bwd", "pswin_attn_bwd_ex", "pswin_window_gather", "pswin_window_scatter_add",
          "pswin_scatter_add_ln_fwd", "pswin_ln_gather_fwd", "pswin_ln_gather_bwd", "pswin_bias_gelu_fwd", "pswin_bias_gelu_bwd",
          "pswin_adamw_flat", "pswin_gemm_skinny", "pswin_gemm_nt", "pswin_gemm_nt_gelu_fwd", "pswin_gemm_nt_gelu_bwd", "pswin_gemm_tn", "pswin_gemm_tn_ring", "pswin_gemm_nt_ring", "pswin_roi_align_fwd", "pswin_roi_align_bwd", "pswin_fc1_gelu_fwd", "pswin_fc1_gelu_bwd", "pswin_stem_conv2_fwd", "pswin_stem_conv3_fwd",
          "pswin_stem_conv3_bwd_stats", "pswin_stem_conv3_bwd_data", "pswin_stem_conv3_wgrad", "pswin_stem_conv2_wgrad",
          "pswin_stem_conv2_bwd", "lib_gemm_fwd", "lib_gemm_dgrad", "lib_gemm_wgrad")
 # hardware MFMA-pipe utilisation of the window-attention kernels: SQ_VALU_MFMA_BUSY_CYCLES of a separate rocprofv3 --pmc pass
 # (tools/pmc_fused.py / tools/pmc_attn.py), summarised into this committed file; the bench line quotes it with its source
-MFMA_BUSY_FILE = "profiles/r02_pmc_window_attention_mfma.json"
+MFMA_BUSY_FILE = "profiles/r03_pmc_window_attention_mfma.json"
 
 
 def cpu_baseline(threads):
@@ -347,7 +347,8 @@ def main():
         for name, recs in kern.items():
             if recs:
                 tot_ms = sum(r[0] for r in recs)
-                st = {"launches": len(recs), "avg_us": round(tot_ms / len(recs) * 1e3, 2), "ms_per_step": round(tot_ms / ksteps, 3),
+                st = {"launches": len(recs), "avg_us": round(tot_ms / len(recs) * 1e3, 2), "max_us": round(max(r[0] for r in recs) * 1e3, 2),
+                      "ms_per_step": round(tot_ms / ksteps, 3),
                       "GBps": round(sum(r[1] for r in recs) / (tot_ms * 1e-3) / 1e9, 1)}
                 fl = sum(r[2] for r in recs)
                 if fl:
@@ -395,7 +396,7 @@ def main():
             pass
         roofline["traffic"], roofline["traffic_source"] = traffic, tnote
         # the window-attention kernels (what BASELINE's metric string and the north star grade), whichever is dominant
-        roofline["window_attention"] = {n: roof(n) for n in ("pswin_win_attn_fused_fwd", "pswin_attn_fwd", "pswin_attn_bwd_ex") if n in stats}
+        roofline["window_attention"] = {n: roof(n) for n in ("pswin_win_attn_fused_fwd", "pswin_qkv_attn_fused_fwd", "pswin_attn_fwd", "pswin_attn_bwd_ex") if n in stats}
         try:
             with open(os.path.join(ROOT, MFMA_BUSY_FILE)) as f:
                 mb = json.load(f)
