@@ -316,6 +316,12 @@ int pswin_gemm_tn(const void* dy, const void* x, float* partial, long long M, in
 int pswin_gemm_tn_ring_supported(long long M, int N, int K);
 int pswin_gemm_tn_ring_splits(long long M, int N, int K, int target_wgs);
 int pswin_gemm_tn_ring(const void* dy, const void* x, void* partial, int partial_dtype, long long M, int N, int K, int splits, void* stream);
+/* The same launch with the bias gradient of the Linear riding along (autograd of HOT:287: db = column sums of dy): dbias_partial
+ * f32 [splits][N] receives, per row split, the column sums of dy over the split's rows (summed by pswin_reduce_jobs like the
+ * weight partials); columns zero_lo <= n < zero_hi are written as exact zeros (the K third of the qkv bias gradient sums to
+ * zero analytically: ops.linear's zero_bias_cols).  dbias_partial = NULL: pswin_gemm_tn_ring. */
+int pswin_gemm_tn_ring_bias(const void* dy, const void* x, void* partial, int partial_dtype, float* dbias_partial, int zero_lo, int zero_hi,
+                            long long M, int N, int K, int splits, void* stream);
 
 typedef struct pswin_transpose_job {
     const void* src; /* bf16 [rows][cols] */

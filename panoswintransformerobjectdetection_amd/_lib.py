@@ -62,6 +62,7 @@ _PROTOTYPES = {
     "pswin_gemm_tn_ring_supported": [ctypes.c_longlong, _i, _i],
     "pswin_gemm_tn_ring_splits": [ctypes.c_longlong, _i, _i, _i],
     "pswin_gemm_tn_ring": [_vp, _vp, _vp, _i, ctypes.c_longlong, _i, _i, _i, _vp],
+    "pswin_gemm_tn_ring_bias": [_vp, _vp, _vp, _i, _vp, _i, _i, ctypes.c_longlong, _i, _i, _i, _vp],
     "pswin_transpose_jobs": [_vp, _i, _vp],
     "pswin_adamw_flat": [_vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _vp, _vp],
     "pswin_adamw_flat_groups": [_vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _vp, _i, _vp, _vp, ctypes.c_double, ctypes.c_double,
@@ -237,18 +238,20 @@ class timed:
         return False
 
 
-def call(name, ref_tensor, *args, algo_bytes=0, algo_flops=0):
-    """Invoke an entry point on the current stream of ref_tensor's device and raise on a non-zero status."""
+def call(name, ref_tensor, *args, algo_bytes=0, algo_flops=0, timed_as=None):
+    """Invoke an entry point on the current stream of ref_tensor's device and raise on a non-zero status.
+    timed_as: the row of the per-kernel timing table the launch is booked under (default: its own name)."""
     lib = load()
     if not ref_tensor.is_cuda:
         raise PswinError(f"{name}: the PanoSwin kernels run on an MI355X (HIP) device only; got a CPU tensor")
+    row = timed_as or name
     with torch.cuda.device(ref_tensor.device):
-        if _TIMED is not None and name in _TIMED:
+        if _TIMED is not None and row in _TIMED:
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
             rc = getattr(lib, name)(*args, stream_of(ref_tensor))
             e.record()
-            _TIMED[name].append((s, e, algo_bytes, algo_flops))
+            _TIMED[row].append((s, e, algo_bytes, algo_flops))
         else:
             rc = getattr(lib, name)(*args, stream_of(ref_tensor))
     check(rc, name)

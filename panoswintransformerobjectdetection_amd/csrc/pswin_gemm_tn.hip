@@ -206,7 +206,7 @@ __device__ inline void wait_frags(Frag (&a)[6], Frag (&b)[3]) {
 template <int WK, int WN, int STAGES, bool OUT_BF16>
 __global__ __launch_bounds__(RING_THREADS, 2) void gemm_tn_ring_kernel(const unsigned short* __restrict__ DY, const unsigned short* __restrict__ X,
                                                                         void* __restrict__ P, int M, int N, int K, int tiles_k, int tiles_n,
-                                                                        int rows_per_split) {
+                                                                        int rows_per_split, float* __restrict__ DB, int zero_lo, int zero_hi) {
     using G = RingGeom<WK, WN, STAGES>;
     constexpr int IA = 6, JB = 3;                      // 16-wide tiles per wave along k (96 columns) / n (48 columns)
     constexpr int RING_STAGE_BYTES = G::STAGE_BYTES, LOADS = G::LOADS;
@@ -266,6 +266,14 @@ __global__ __launch_bounds__(RING_THREADS, 2) void gemm_tn_ring_kernel(const uns
     for (int i = 0; i < IA; ++i)
 #pragma unroll
         for (int j = 0; j < JB; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // Bias gradient (DB != null): the column sums of dY over this split's rows are one more product, ones^T . dY, on the dY fragments
+    // the wave already holds -- 3 MFMAs per 32-row half on top of 18, in the waves of the first k block of the first k tile only.
+    // It replaces a separate pass over dY (pswin_colsum: 12 launches per step for the qkv biases).
+    const bool sum_db = DB != nullptr && tk == 0 && wk == 0;
+    f32x4 accs[JB];
+#pragma unroll
+    for (int j = 0; j < JB; ++j) accs[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bf16x8 ones = __builtin_bit_cast(bf16x8, u32x4{0x3F803F80u, 0x3F803F80u, 0x3F803F80u, 0x3F803F80u});
 
     // transposed reads: lane (c = 4 q + p, g) addresses row (32 ks + 8 g + q), 8-byte piece p of the 16-column block cb of a panel;
     // block swizzle f = ((q >> 1) & 1) | ((g & 1) << 1) is a lane constant.  One base register per 16-column block position cb and
@@ -322,6 +330,10 @@ __global__ __launch_bounds__(RING_THREADS, 2) void gemm_tn_ring_kernel(const uns
             __builtin_amdgcn_sched_barrier(0);
         };
         [&]<int... Ns>(std::integer_sequence<int, Ns...>) { (slot(std::integral_constant<int, Ns>{}), ...); }(std::make_integer_sequence<int, 18>{});
+        if (sum_db) {
+#pragma unroll
+            for (int j = 0; j < JB; ++j) accs[j] = mfma32(ones, bfr[j], accs[j]);
+        }
     };
     auto read_all = [&](auto ks_tag, unsigned stage_off, Frag (&a)[6], Frag (&b)[3]) {
         [&]<int... Ns>(std::integer_sequence<int, Ns...>) { (read_n(ks_tag, std::integral_constant<int, Ns>{}, stage_off, a, b), ...); }(std::make_integer_sequence<int, 18>{});
@@ -361,6 +373,14 @@ __global__ __launch_bounds__(RING_THREADS, 2) void gemm_tn_ring_kernel(const uns
         phase(KS0{}, std::false_type{}, 0u, a1, b1, a0, b0);                 // the last slab's second half
     }
 
+    // accs[j][e] = sum over the split's rows of dY[row][n = n0 + 48 wn + 16 j + c], the same in every element and lane group
+    if (sum_db && g == 0) {
+#pragma unroll
+        for (int j = 0; j < JB; ++j) {
+            const int n = n0 + wn * 48 + 16 * j + c;
+            if (n < N) DB[(size_t)split * N + n] = (n >= zero_lo && n < zero_hi) ? 0.f : accs[j][0];
+        }
+    }
     // acc[i][j][e] = partial dW[n = n0 + 48 wn + 16 j + c][k = k0 + 96 wk + 16 i + 4 g + e]
 #pragma unroll
     for (int j = 0; j < JB; ++j) {
@@ -381,7 +401,7 @@ __global__ __launch_bounds__(RING_THREADS, 2) void gemm_tn_ring_kernel(const uns
 }
 
 template <int WK, int WN, int STAGES, bool OUT_BF16>
-int launch_tn_ring(const void* dy, const void* x, void* partial, int M, int N, int K, int splits, hipStream_t st) {
+int launch_tn_ring(const void* dy, const void* x, void* partial, int M, int N, int K, int splits, hipStream_t st, float* db, int zero_lo, int zero_hi) {
     using G = RingGeom<WK, WN, STAGES>;
     constexpr size_t lds = (size_t)STAGES * G::STAGE_BYTES;
     static std::atomic<unsigned long long> configured{0};
@@ -390,7 +410,7 @@ int launch_tn_ring(const void* dy, const void* x, void* partial, int M, int N, i
     const int rows_per_split = ((M + splits - 1) / splits + MSTEP - 1) / MSTEP * MSTEP;
     hipLaunchKernelGGL((gemm_tn_ring_kernel<WK, WN, STAGES, OUT_BF16>), dim3(tiles_k * tiles_n * splits), dim3(RING_THREADS), lds, st,
                        reinterpret_cast<const unsigned short*>(dy), reinterpret_cast<const unsigned short*>(x), partial, M, N, K, tiles_k, tiles_n,
-                       rows_per_split);
+                       rows_per_split, db, zero_lo, zero_hi);
     PSWIN_LAUNCH_RET();
 }
 
@@ -458,17 +478,31 @@ int pswin_gemm_tn_ring_splits(long long M, int N, int K, int target_wgs) {
     return s < 1 ? 1 : s;
 }
 
-int pswin_gemm_tn_ring(const void* dy, const void* x, void* partial, int partial_dtype, long long M, int N, int K, int splits, void* stream) {
+int pswin_gemm_tn_ring_bias(const void* dy, const void* x, void* partial, int partial_dtype, float* dbias_partial, int zero_lo, int zero_hi, long long M,
+                            int N, int K, int splits, void* stream) {
     PSWIN_CHECK_ARG(dy && x && partial && pswin_gemm_tn_ring_supported(M, N, K) && splits >= 1 && splits <= M / 64 && valid_dtype(partial_dtype));
     PSWIN_CHECK_ARG(aligned16(dy) && aligned16(x) && aligned16(partial));
+    PSWIN_CHECK_ARG(zero_lo >= 0 && zero_hi >= zero_lo && zero_hi <= N);
     const bool bf = partial_dtype == PSWIN_BF16;
     const hipStream_t st = (hipStream_t)stream;
+    float* db = dbias_partial;
+    const int m = (int)M;
     switch (ring_geom(N, K)) {
-        case 0: return bf ? launch_tn_ring<2, 4, 3, true>(dy, x, partial, (int)M, N, K, splits, st) : launch_tn_ring<2, 4, 3, false>(dy, x, partial, (int)M, N, K, splits, st);
-        case 1: return bf ? launch_tn_ring<1, 8, 2, true>(dy, x, partial, (int)M, N, K, splits, st) : launch_tn_ring<1, 8, 2, false>(dy, x, partial, (int)M, N, K, splits, st);
-        case 2: return bf ? launch_tn_ring<4, 2, 2, true>(dy, x, partial, (int)M, N, K, splits, st) : launch_tn_ring<4, 2, 2, false>(dy, x, partial, (int)M, N, K, splits, st);
+        case 0:
+            return bf ? launch_tn_ring<2, 4, 3, true>(dy, x, partial, m, N, K, splits, st, db, zero_lo, zero_hi)
+                      : launch_tn_ring<2, 4, 3, false>(dy, x, partial, m, N, K, splits, st, db, zero_lo, zero_hi);
+        case 1:
+            return bf ? launch_tn_ring<1, 8, 2, true>(dy, x, partial, m, N, K, splits, st, db, zero_lo, zero_hi)
+                      : launch_tn_ring<1, 8, 2, false>(dy, x, partial, m, N, K, splits, st, db, zero_lo, zero_hi);
+        case 2:
+            return bf ? launch_tn_ring<4, 2, 2, true>(dy, x, partial, m, N, K, splits, st, db, zero_lo, zero_hi)
+                      : launch_tn_ring<4, 2, 2, false>(dy, x, partial, m, N, K, splits, st, db, zero_lo, zero_hi);
         default: return PSWIN_ERR_UNSUPPORTED;
     }
+}
+
+int pswin_gemm_tn_ring(const void* dy, const void* x, void* partial, int partial_dtype, long long M, int N, int K, int splits, void* stream) {
+    return pswin_gemm_tn_ring_bias(dy, x, partial, partial_dtype, nullptr, 0, 0, M, N, K, splits, stream);
 }
 
 int pswin_gemm_tn(const void* dy, const void* x, float* partial, long long M, int N, int K, int splits, void* stream) {

@@ -700,6 +700,8 @@ GEMM_TN_RING = os.environ.get("PSWIN_GEMM_TN_RING", "1") != "0"
 # partial slabs of the row splits in bf16 (what the library's batched GEMM writes; half the slab traffic) or f32
 GEMM_TN_RING_BF16 = os.environ.get("PSWIN_GEMM_TN_RING_BF16", "1") != "0"
 GEMM_TN_RING_WGS = int(os.environ.get("PSWIN_GEMM_TN_RING_WGS", "0"))
+# the Linear's bias gradient (column sums of dy) from the weight-gradient launch instead of a pass of its own; 0: pswin_colsum (A/B)
+GEMM_TN_RING_BIAS = os.environ.get("PSWIN_GEMM_TN_RING_BIAS", "1") != "0"
 
 
 def gemm_tn_ring_splits(M, N, K):
@@ -709,15 +711,23 @@ def gemm_tn_ring_splits(M, N, K):
     return int(_lib.load().pswin_gemm_tn_ring_splits(M, N, K, GEMM_TN_RING_WGS))
 
 
-def gemm_tn_ring(dy, x, splits, out_dtype=torch.float32):
-    """[splits, N, K] partial sums of dy^T x over `splits` row ranges (dy [M, N], x [M, K] bf16) in f32 or bf16."""
+def gemm_tn_ring(dy, x, splits, out_dtype=torch.float32, bias_sums=False, zero_cols=None):
+    """[splits, N, K] partial sums of dy^T x over `splits` row ranges (dy [M, N], x [M, K] bf16) in f32 or bf16.
+    bias_sums=True: also the f32 [splits, N] column sums of dy per row range (the Linear's bias-gradient partials, from the same
+    launch; zero_cols=(lo, hi) columns written as zeros) -> (partials, bias partials)."""
     dy, x = dy.contiguous(), x.contiguous()
     M, N = dy.shape
     K = x.shape[1]
     part = torch.empty(splits, N, K, dtype=out_dtype, device=x.device)
-    call("pswin_gemm_tn_ring", x, ptr(dy), ptr(x), ptr(part), dtype_code(part), M, N, K, int(splits),
-         algo_bytes=2 * (M * K + M * N) + part.element_size() * splits * N * K, algo_flops=2 * M * K * N)
-    return part
+    if not bias_sums:
+        call("pswin_gemm_tn_ring", x, ptr(dy), ptr(x), ptr(part), dtype_code(part), M, N, K, int(splits),
+             algo_bytes=2 * (M * K + M * N) + part.element_size() * splits * N * K, algo_flops=2 * M * K * N)
+        return part
+    dbp = torch.empty(splits, N, dtype=torch.float32, device=x.device)
+    zlo, zhi = (0, 0) if zero_cols is None else (int(zero_cols[0]), int(zero_cols[1]))
+    call("pswin_gemm_tn_ring_bias", x, ptr(dy), ptr(x), ptr(part), dtype_code(part), ptr(dbp), zlo, zhi, M, N, K, int(splits),
+         algo_bytes=2 * (M * K + M * N) + part.element_size() * splits * N * K, algo_flops=2 * M * K * N, timed_as="pswin_gemm_tn_ring")
+    return part, dbp
 
 
 def gemm_nt(x2d, w, bias=None, tile_m=0):
@@ -844,8 +854,14 @@ def linear_backward(x, wb, dy, weight, bias, zero_bias_cols, need_dx, wbt=None):
                 dx = dy @ wb
     sp = gemm_tn_splits(M, N, K) if dy.dtype == torch.bfloat16 else 0
     rs = gemm_tn_ring_splits(M, N, K) if (dy.dtype == torch.bfloat16 and not sp) else 0
-    if rs:                                                   # stages 1-3: the ring-pipelined HIP weight-gradient kernel
-        part, ch, sp = gemm_tn_ring(dy, x, rs, torch.bfloat16 if (GEMM_TN_RING_BF16 and rs > 1) else torch.float32), rs, rs
+    db_part = None
+    if rs:                                                   # the ring-pipelined HIP weight-gradient kernel; the bias gradient rides along
+        pdt = torch.bfloat16 if (GEMM_TN_RING_BF16 and rs > 1) else torch.float32
+        if bias is not None and GEMM_TN_RING_BIAS:
+            part, db_part = gemm_tn_ring(dy, x, rs, pdt, bias_sums=True, zero_cols=zero_bias_cols)
+        else:
+            part = gemm_tn_ring(dy, x, rs, pdt)
+        ch, sp = rs, rs
     elif sp:                                                 # (opt-in) the two-stage HIP kernel of round 2, f32 partial slabs
         part, ch = gemm_tn(dy, x, sp), sp
     else:
@@ -859,7 +875,10 @@ def linear_backward(x, wb, dy, weight, bias, zero_bias_cols, need_dx, wbt=None):
         dw = sum_rows(part, ch, N * K, out=grad_slot(weight), owners=(weight,)).view(N, K)
     elif sp:
         dw = part.view(N, K).float()
-    db = colsum(dy, zero_bias_cols, owners=(bias,)) if bias is not None else None
+    if db_part is not None:
+        db = sum_rows(db_part, db_part.shape[0], N, owners=(bias,))
+    else:
+        db = colsum(dy, zero_bias_cols, owners=(bias,)) if bias is not None else None
     return dx, dw, db
 
 

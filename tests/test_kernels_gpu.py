@@ -905,6 +905,22 @@ def test_gemm_tn_ring_against_torch(ops, M, N, K, splits, out_bf16):
             want = dy[lo:hi].float().t() @ x[lo:hi].float()
             assert torch.allclose(part[s_], want, rtol=2e-3, atol=2e-3 * float(ref.abs().max()))
     assert lib.pswin_gemm_tn_ring_supported(M, 200, K) == 0 and lib.pswin_gemm_tn_ring_supported(M, 576, 96) == 0
+    # the bias gradient riding along (pswin_gemm_tn_ring_bias): same weight partials bit for bit, per-split column sums of dy, the
+    # zero range written as exact zeros
+    zc = (N // 3 // 16 * 16, 2 * (N // 3) // 16 * 16)
+    part2, dbp = ops.gemm_tn_ring(dy, x, sp, torch.bfloat16 if out_bf16 else torch.float32, bias_sums=True, zero_cols=zc)
+    assert torch.equal(part2, part) and dbp.shape == (sp, N)
+    want_db = dy.float().sum(0)
+    want_db[zc[0]:zc[1]] = 0
+    got_db = dbp.sum(0)
+    assert torch.allclose(got_db, want_db, rtol=1e-4, atol=1e-4 * float(dy.float().abs().sum(0).max())), (got_db - want_db).abs().max()
+    assert bool((dbp[:, zc[0]:zc[1]] == 0).all())
+    if sp > 1:
+        rows = -(-(-(-M // sp)) // 64) * 64
+        lo, hi = min((sp - 1) * rows, M), M
+        w_last = dy[lo:hi].float().sum(0)
+        w_last[zc[0]:zc[1]] = 0
+        assert torch.allclose(dbp[sp - 1], w_last, rtol=1e-4, atol=1e-3)
 
 
 @pytest.mark.parametrize("M,C,tile", [(16384, 384, 128), (4096, 768, 64), (333, 192, 64), (19600, 384, 128)])
