@@ -650,6 +650,10 @@ def gemm_nt_supported(x2d, n_out):
             and bool(_lib.load().pswin_gemm_nt_supported(x2d.shape[0], x2d.shape[1], n_out)))
 
 
+# PSWIN_GEMM_NT_ALL=1: every supported shape on the HIP kernel, also the stage-3 ones the isolated measurements gave to the library (A/B)
+GEMM_NT_ALL = os.environ.get("PSWIN_GEMM_NT_ALL", "0") == "1"
+
+
 def gemm_nt_tile(M, K, N):
     """Row-tile height (64 / 128) with which pswin_gemm_nt computes [M, K] x [N, K]^T, or 0 = leave it to the library.
     From profiles/r02_gemm_nt_vs_library.txt (MI355X, PanoSwin-T shapes at batch 8): the HIP kernel wins wherever the rows fill
@@ -657,7 +661,7 @@ def gemm_nt_tile(M, K, N):
     128-row tiles once they give every CU two rounds of work."""
     if not GEMM_NT or not bool(_lib.load().pswin_gemm_nt_supported(M, K, N)):
         return 0
-    if M < 8192 and not (N <= 768 and K <= 1536):
+    if M < 8192 and not (N <= 768 and K <= 1536) and not GEMM_NT_ALL:
         return 0
     return 128 if -(-M // 128) * (N // 192) >= 512 else 64
 
@@ -767,6 +771,11 @@ def gemm_nt_ring(x2d, w, bias=None):
     return y
 
 
+# PSWIN_SKINNY_FC2_DGRAD=1: stage-0 fc2 data gradient ([M, 96] x [96, 384]) on the streaming kernel instead of the library (83 us per launch inside
+# the step).  Measured same box: the streaming kernel takes 91 us there, 717.6 vs 724.8 panoramas/s -- off by default (profiles/r03_ab_small_switches.txt)
+SKINNY_FC2_DGRAD = os.environ.get("PSWIN_SKINNY_FC2_DGRAD", "0") == "1"
+
+
 def skinny_gemm_supported(x2d, n_out):
     """bf16 rows x a small weight: the shapes pswin_gemm_skinny is instantiated for (stage-0 projections, stage-1 proj)"""
     return (x2d.dtype == torch.bfloat16 and x2d.is_cuda and x2d.shape[0] >= 4096
@@ -843,9 +852,9 @@ def linear_backward(x, wb, dy, weight, bias, zero_bias_cols, need_dx, wbt=None):
     dx = None
     if need_dx:
         # data gradient with the streaming kernel (weight transposed while it is staged) where that beats the library:
-        # the three stage-0 shapes with 96 output columns
+        # the three stage-0 shapes with 96 output columns and the stage-0 fc2 (96 -> 384 columns)
         tile = gemm_nt_tile(M, N, K) if (wbt is not None and dy.dtype == torch.bfloat16) else 0
-        if K == 96 and N in (96, 288, 384) and skinny_gemm_supported(dy, K):
+        if ((K == 96 and N in (96, 288, 384)) or (N == 96 and K == 384 and SKINNY_FC2_DGRAD)) and skinny_gemm_supported(dy, K):
             dx = skinny_gemm(dy, wb, None, transpose_w=True)
         elif tile:
             dx = gemm_nt(dy, wbt, None, tile)
