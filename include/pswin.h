@@ -410,6 +410,17 @@ int pswin_fc1_gelu_partial_rows(long long M);                      /* rows of N 
 int pswin_fc1_gelu_bwd(const void* x, const void* w, const float* bias, const void* dh, void* dy, float* dbias,
                        float* workspace, long long M, int K, int N, void* stream);
 
+/* Stage-0 Mlp backward, first half, as ONE pass (round 3): g = (dy . W2) * gelu'(x . W1^T + b1) -- fc2's data gradient (HOT:58), the
+ * backward of nn.GELU (HOT:57) on the recomputed fc1 pre-activation (HOT:56) and the fc1 bias gradient's partial sums; dh = dy . W2
+ * (201 MB per block at batch 8) is never written.  x, dy [M, C] bf16 rows; w1 = fc1.weight [hidden, C], w2 = fc2.weight [C, hidden]
+ * bf16; b1 f32 [hidden] or NULL; g [M, hidden] bf16; workspace f32 [pswin_mlp0_bwd_partial_rows(M)][hidden] receives the
+ * per-workgroup column sums of g; dbias1 f32 [hidden] their fixed-order sum, or NULL (partial rows only); workspace = NULL: no column
+ * sums (a caller that runs fc1's weight gradient on pswin_gemm_tn_ring_bias gets them from that launch).  C = 96, hidden = 384. */
+int pswin_mlp0_bwd_supported(int C, int hidden);
+int pswin_mlp0_bwd_partial_rows(long long M);
+int pswin_mlp0_bwd(const void* x, const void* w1, const float* b1, const void* dy, const void* w2, void* g, float* dbias1, float* workspace,
+                   long long M, int C, int hidden, void* stream);
+
 /* Column sums of a row-major [M, N] matrix in fp32: out[n] = sum_m x[m][n] (fixed summation order).  The bias
  * gradient of every Linear on the path (autograd of nn.Linear, HOT:50-52, 236, 323) and the reduction of split-K
  * weight-gradient partials.  N % 8 == 0; workspace: f32, pswin_colsum_workspace(M, N, dtype) elements. */

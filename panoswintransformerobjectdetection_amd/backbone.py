@@ -81,6 +81,9 @@ class Mlp(nn.Module):
     def forward_nobias2(self, x, cd):
         """fc2(gelu(fc1 x + b1)) WITHOUT fc2's bias (the caller adds it with the residual): bias + GELU in one HIP pass"""
         x2 = x.to(cd).reshape(-1, x.shape[-1])
+        if self.fc1.bias is not None and ops.mlp0_fused_supported(x2, self.fc1.weight.shape[0]):
+            # stage 0: one autograd node; its backward runs fc2's data gradient and the GELU backward in one pass
+            return ops.mlp0_fused(x2, self.fc1, self.fc2).view(*x.shape[:-1], self.fc2.weight.shape[0])
         if self.fc1.bias is not None and ops.fc1_gelu_supported(x2, self.fc1.weight.shape[0]):
             lp = self.fc1.__dict__.get("_lowp")                    # stage 0: fc1 + bias + GELU in one streaming kernel
             h = ops.fc1_gelu(x2, self.fc1.weight, self.fc1.bias, lp[0] if lp is not None else None)

@@ -253,6 +253,176 @@ int launch(const void* x, const void* w, const float* bias, void* y, int M, int 
     PSWIN_LAUNCH_RET();
 }
 
+
+// ---- stage-0 Mlp backward, first half, in one pass (round 3) ----------------------------------------------------------------------
+// g = (dy . W2) * gelu'(x . W1^T + b1)   -- fc2's data gradient (HOT:58) and the backward of nn.GELU (HOT:57) with fc1's
+// pre-activation recomputed (HOT:56), + the per-workgroup column sums of g (the fc1 bias gradient).  As two launches this was the
+// library's slowest remaining GEMM (83 us: [262144, 96] x [96, 384]) writing dh = dy . W2 (201 MB at batch 8) and pswin_fc1_gelu_bwd
+// reading it back; here dh exists only in accumulators.  Both weights are resident in LDS as MFMA A-operand row fragments (W1 as it
+// is, W2 transposed while it is staged: 2 x 72 KB, one 8-wave workgroup per CU), a wave streams 16 rows of x and of dy (a row's
+// 16-byte chunk is a B fragment) and runs the 384 output columns in two halves of 12 column tiles, two accumulator sets (pre, dh)
+// of 48 registers each; weight fragments in batches of 6, double buffered in registers as in skinny_gemm_kernel.
+constexpr int M0_THREADS = 512, M0_WAVES = 8, M0_K = 96, M0_N = 384, M0_KS = 3, M0_HT = 12;
+constexpr int M0_LDS = 2 * M0_N * 192 + M0_N * 4 + M0_WAVES * M0_N * 4;
+
+template <bool SUMS>
+__global__ __launch_bounds__(M0_THREADS, 2) void mlp0_bwd_kernel(const void* __restrict__ x, const void* __restrict__ w1, const float* __restrict__ b1,
+                                                                 const void* __restrict__ dy, const void* __restrict__ w2, void* __restrict__ gout,
+                                                                 float* __restrict__ partial, int M) {
+    constexpr int K = M0_K, N = M0_N, KS = M0_KS;
+    auto woff = [](int row, int chunk) { return row * 192 + ((((chunk & ~3) | ((chunk ^ (row >> 1)) & 3))) << 4); };
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* w1l = smem;                                                    // [N][192]: W1 rows (output column n, contraction k)
+    char* w2l = smem + N * 192;                                          // [N][192]: W2^T rows (hidden column n, contraction k2)
+    float* bl = reinterpret_cast<float*>(smem + 2 * N * 192);            // [N]
+    float* cs = bl + N;                                                  // [8 waves][N] column sums
+    for (int i = threadIdx.x; i < N * (K / 8); i += M0_THREADS) {
+        const int row = i / (K / 8), ch = i - row * (K / 8);
+        *reinterpret_cast<u32x4*>(w1l + woff(row, ch)) = reinterpret_cast<const u32x4*>(w1)[i];
+    }
+    {
+        const unsigned short* ws = reinterpret_cast<const unsigned short*>(w2);      // fc2.weight [96][384] -> image[n][k2]
+        for (int i = threadIdx.x; i < K * (N / 8); i += M0_THREADS) {
+            const int k = i / (N / 8), n0 = (i - k * (N / 8)) * 8;
+            const u32x4 v = *reinterpret_cast<const u32x4*>(ws + (size_t)k * N + n0);
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                *reinterpret_cast<unsigned short*>(w2l + woff(n0 + 2 * d, k >> 3) + 2 * (k & 7)) = (unsigned short)(v[d] & 0xffffu);
+                *reinterpret_cast<unsigned short*>(w2l + woff(n0 + 2 * d + 1, k >> 3) + 2 * (k & 7)) = (unsigned short)(v[d] >> 16);
+            }
+        }
+    }
+    for (int i = threadIdx.x; i < N; i += M0_THREADS) bl[i] = b1 ? b1[i] : 0.f;
+    if constexpr (SUMS)
+        for (int i = threadIdx.x; i < M0_WAVES * N; i += M0_THREADS) cs[i] = 0.f;
+    __syncthreads();
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int c = lane & 15, g = lane >> 4;
+    const rsrc_t xs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(x), 0, (int)((size_t)M * K * 2), 0x00020000);
+    const rsrc_t ds = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(dy), 0, (int)((size_t)M * K * 2), 0x00020000);
+    const rsrc_t gs = __builtin_amdgcn_make_buffer_rsrc(gout, 0, (int)((size_t)M * N * 2), 0x00020000);
+    const int ntiles = (M + 15) / 16;
+    const int d0 = 8 * (g >> 1) + 16 * (g & 1);
+    const int lane_off = c * 192 + (((g ^ (c >> 1)) & 3) << 4);
+    bf16x8 bx[KS], bd[KS];
+    auto load_b = [&](int tile) {
+        const unsigned row = (unsigned)tile * 16 + c;
+        const unsigned off = row < (unsigned)M ? row * (unsigned)(K * 2) + 16u * g : 0xFFFFFF00u;          // rows >= M: zeros
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const unsigned o = off == 0xFFFFFF00u ? off : off + 64u * s;
+            bx[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xs, o, 0, 0));
+            bd[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(ds, o, 0, 0));
+        }
+    };
+    const int tile0 = blockIdx.x * M0_WAVES + wave, tstep = gridDim.x * M0_WAVES;
+    auto row_tile = [&](int tile) {
+        const unsigned row = (unsigned)tile * 16 + c;
+        const unsigned base = row < (unsigned)M ? row * (unsigned)(N * 2) + 2u * d0 : 0xFFFFFF00u;
+        // the bias quads are the same for every tile: left to itself the compiler reads all 96 values once in front of the tile
+        // loop and spills them; an opaque zero in the address keeps the (cheap) LDS reads in the epilogue
+        int zb = 0;
+        asm volatile("" : "+v"(zb));
+        const float* blt = bl + zb;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            f32x4 ap[M0_HT], ad[M0_HT];
+#pragma unroll
+            for (int t = 0; t < M0_HT; ++t) {
+                ap[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                ad[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            // per contraction step the half's 24 fragments [W1 tiles 0..11 | W2^T tiles 0..11] in batches of 6
+            constexpr int BT = 6, BPS = 2 * M0_HT / BT, NB = KS * BPS;
+            bf16x8 a[2][BT];
+            // fragment (column tile t of this half, step s) of an image: lane part + 3072 t + 64 s -- woff(16 nt + c, 4 s + g) written out,
+            // with one base per (image, half) so that every immediate stays below the 64 KB of a ds_read offset (bases the compiler
+            // derives itself for the second image were spilled and reloaded per tile, each reload waiting out the previous tile's stores)
+            const char* img1 = w1l + lane_off + half * (M0_HT * 3072);
+            const char* img2 = w2l + lane_off + half * (M0_HT * 3072);
+            auto read_batch = [&](int bi, bf16x8 (&dst)[BT]) {
+                const int s_ = bi / BPS, e0 = (bi - s_ * BPS) * BT;
+#pragma unroll
+                for (int j = 0; j < BT; ++j) {
+                    const int e = e0 + j;
+                    dst[j] = *reinterpret_cast<const bf16x8*>((e < M0_HT ? img1 : img2) + 3072 * (e < M0_HT ? e : e - M0_HT) + 64 * s_);
+                }
+            };
+            read_batch(0, a[0]);
+#pragma unroll
+            for (int bi = 0; bi < NB; ++bi) {
+                if (bi + 1 < NB) read_batch(bi + 1, a[(bi + 1) & 1]);
+                const int s_ = bi / BPS, e0 = (bi - s_ * BPS) * BT;
+#pragma unroll
+                for (int j = 0; j < BT; ++j) {
+                    const int e = e0 + j;
+                    if (e < M0_HT) ap[e] = mfma32(a[bi & 1][j], bx[s_], ap[e]);
+                    else ad[e - M0_HT] = mfma32(a[bi & 1][j], bd[s_], ad[e - M0_HT]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // the next tile's rows are requested once the last MFMA has consumed the registers, before this half's stores
+            if (half == 1 && tile + tstep < ntiles) load_b(tile + tstep);
+            __builtin_amdgcn_sched_barrier(0);
+            // ap[t][e] = pre-activation - b1, ad[t][e] = dh at [row c][column 192 half + 16 t + 4 g + e]
+#pragma unroll
+            for (int np = 0; np < M0_HT / 2; ++np) {
+                const int col = 192 * half + 32 * np;
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(blt + col + 4 * g);
+                const f32x4 b1v = *reinterpret_cast<const f32x4*>(blt + col + 16 + 4 * g);
+                const f32x4 p0 = ap[2 * np] + b0, p1 = ap[2 * np + 1] + b1v;
+                f32x4 v0, v1;
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {
+                    // the forward pass rounds the pre-activation to nothing (it is never stored) and h to bf16; dh is an f32 accumulator
+                    const gelu_f32x2 g0 = gelu_grad_f2(gelu_f32x2{p0[e], p0[e + 1]}), g1 = gelu_grad_f2(gelu_f32x2{p1[e], p1[e + 1]});
+                    v0[e] = ad[2 * np][e] * g0[0];
+                    v0[e + 1] = ad[2 * np][e + 1] * g0[1];
+                    v1[e] = ad[2 * np + 1][e] * g1[0];
+                    v1[e + 1] = ad[2 * np + 1][e + 1] * g1[1];
+                }
+                const unsigned off = base == 0xFFFFFF00u ? base : base + 2u * col;
+                __builtin_amdgcn_raw_buffer_store_b128(pack_row8(v0, v1), gs, off, 0, 0);
+                // column sums over the tile's 16 rows (the lanes c of a group share the columns); rows >= M contribute zeros (their
+                // dy rows read as zeros, so dh = 0).  32 DPP adds per column pair: the caller that runs the fc1 weight gradient on
+                // pswin_gemm_tn_ring_bias gets the same sums from its MFMAs and asks for none here (workspace = NULL).
+                if constexpr (SUMS) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float s0 = row16_sum(v0[e]), s1 = row16_sum(v1[e]);
+                        if (c == 0) {
+                            cs[wave * N + col + 4 * g + e] += s0;
+                            cs[wave * N + col + 16 + 4 * g + e] += s1;
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);               // one column pair at a time (interleaved, the six pairs' temporaries spill)
+            }
+        }
+    };
+    if (tile0 < ntiles) {
+        load_b(tile0);
+        row_tile(tile0);
+        for (int tile = tile0 + tstep; tile < ntiles; tile += tstep) row_tile(tile);
+    }
+    if constexpr (SUMS) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < N; i += M0_THREADS) {
+            float sum = 0.f;
+#pragma unroll
+            for (int w = 0; w < M0_WAVES; ++w) sum += cs[w * N + i];
+            partial[(size_t)blockIdx.x * N + i] = sum;
+        }
+    }
+}
+
+constexpr int M0_MAX_GRID = 256;                 // one 8-wave workgroup per CU (147 KB of weights in LDS)
+inline int mlp0_grid(long long M) {
+    const long long ntiles = (M + 15) / 16, g = (ntiles + M0_WAVES - 1) / M0_WAVES;
+    return (int)(g > M0_MAX_GRID ? M0_MAX_GRID : g);
+}
+
 }  // namespace
 
 extern "C" {
@@ -296,6 +466,36 @@ int pswin_fc1_gelu_bwd(const void* x, const void* w, const float* bias, const vo
     const int rc = launch<3, 24, 1, 2>(x, w, bias, dy, (int)M, 0, dh, workspace, (hipStream_t)stream, &grid);
     if (rc) return rc;
     if (dbias) launch_colsum(workspace, grid, N, dbias, (hipStream_t)stream);   // else: partial rows only
+    PSWIN_LAUNCH_RET();
+}
+
+/* Stage-0 Mlp backward, first half (autograd of HOT:56-58): g = (dy . W2) * gelu'(x . W1^T + b1) in one pass, dh never stored.
+ * x [M, C], dy [M, C] bf16 rows; w1 = fc1.weight [hidden, C], w2 = fc2.weight [C, hidden] bf16; b1 f32 [hidden]; g [M, hidden] bf16;
+ * workspace f32 [pswin_mlp0_bwd_partial_rows(M)][hidden] receives the per-workgroup column sums of g, dbias1 (or NULL: partial rows
+ * only) their fixed-order sum; workspace = NULL: no column sums at all (the caller takes them from pswin_gemm_tn_ring_bias). */
+int pswin_mlp0_bwd_supported(int C, int hidden) { return C == M0_K && hidden == M0_N; }
+
+int pswin_mlp0_bwd_partial_rows(long long M) {
+    if (M <= 0 || M > 0x7fffffffll) return PSWIN_ERR_ARG;
+    return mlp0_grid(M);
+}
+
+int pswin_mlp0_bwd(const void* x, const void* w1, const float* b1, const void* dy, const void* w2, void* g, float* dbias1, float* workspace,
+                   long long M, int C, int hidden, void* stream) {
+    PSWIN_CHECK_ARG(x && w1 && dy && w2 && g && M > 0 && pswin_mlp0_bwd_supported(C, hidden) && (workspace || !dbias1));
+    PSWIN_CHECK_ARG(M * (long long)hidden * 2 < 0xFFFFFF00ll && aligned16(x) && aligned16(w1) && aligned16(dy) && aligned16(w2) && aligned16(g));
+    const int grid = mlp0_grid(M);
+    const hipStream_t st = (hipStream_t)stream;
+    if (workspace) {
+        static std::atomic<unsigned long long> configured{0};
+        if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&mlp0_bwd_kernel<true>), M0_LDS, configured)) return rc;
+        hipLaunchKernelGGL(mlp0_bwd_kernel<true>, dim3(grid), dim3(M0_THREADS), M0_LDS, st, x, w1, b1, dy, w2, g, workspace, (int)M);
+        if (dbias1) launch_colsum(workspace, grid, hidden, dbias1, st);
+    } else {
+        static std::atomic<unsigned long long> configured{0};
+        if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&mlp0_bwd_kernel<false>), M0_LDS, configured)) return rc;
+        hipLaunchKernelGGL(mlp0_bwd_kernel<false>, dim3(grid), dim3(M0_THREADS), M0_LDS, st, x, w1, b1, dy, w2, g, workspace, (int)M);
+    }
     PSWIN_LAUNCH_RET();
 }
 

@@ -954,6 +954,67 @@ class _Fc1Gelu(torch.autograd.Function):
         return dx, dw, db, None
 
 
+class _Mlp0(torch.autograd.Function):
+    """fc2_nobias(gelu(fc1(x))) of the stage-0 Mlp (HOT:50-58, C = 96) as one autograd node.  Forward: pswin_fc1_gelu_fwd (h is kept,
+    the pre-activation is not) + the streaming GEMM.  Backward: g = (dy W2) * gelu'(x W1^T + b1) in ONE pass (pswin_mlp0_bwd: fc2's
+    data gradient never reaches memory), then dx = g W1 (streaming GEMM), dW1 = g^T x and dW2 = dy^T h (ring kernel)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, w1_lp, w2_lp):
+        x = x.contiguous()
+        w1b = (w1_lp if w1_lp is not None else w1.to(x.dtype)).contiguous()
+        w2b = (w2_lp if w2_lp is not None else w2.to(x.dtype)).contiguous()
+        M, K = x.shape
+        N = w1b.shape[0]
+        h = torch.empty(M, N, dtype=x.dtype, device=x.device)
+        b = b1.detach().float().contiguous()
+        call("pswin_fc1_gelu_fwd", x, ptr(x), ptr(w1b), ptr(b), ptr(h), M, K, N, algo_bytes=2 * M * (K + N))
+        y = skinny_gemm(h, w2b, None)
+        ctx.save_for_backward(x, w1b, b, h, w2b)
+        ctx.params = (w1, b1, w2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w1b, b, h, w2b = ctx.saved_tensors
+        w1, b1, w2 = ctx.params
+        M, K = x.shape
+        N = w1b.shape[0]
+        dy = dy.to(x.dtype).contiguous()
+        g = torch.empty(M, N, dtype=x.dtype, device=x.device)
+        lib = _lib.load()
+        ring_bias = GEMM_TN_RING_BIAS and gemm_tn_ring_splits(M, N, K) > 0     # the fc1 weight-gradient launch also sums g's columns
+        ws = None
+        if not ring_bias:
+            rows = lib.pswin_mlp0_bwd_partial_rows(M)
+            ws = torch.empty(rows, N, dtype=torch.float32, device=x.device)
+        call("pswin_mlp0_bwd", x, ptr(x), ptr(w1b), ptr(b), ptr(dy), ptr(w2b), ptr(g), None, ptr(ws), M, K, N,
+             algo_bytes=2 * M * (2 * K + N), algo_flops=4 * M * K * N)
+        if ring_bias:
+            dx, dw1, db1 = linear_backward(x, w1b, g, w1, b1, None, ctx.needs_input_grad[0])
+        else:
+            db1 = sum_rows(ws, rows, N, owners=(b1,))
+            dx, dw1, _ = linear_backward(x, w1b, g, w1, None, None, ctx.needs_input_grad[0])
+        _, dw2, _ = linear_backward(h, w2b, dy, w2, None, None, False)
+        return dx, dw1, db1, dw2, None, None
+
+
+# PSWIN_MLP0_FUSED=0: the stage-0 Mlp as fc1 + GELU node and fc2 node (library data gradient, pswin_fc1_gelu_bwd) -- A/B
+MLP0_FUSED = os.environ.get("PSWIN_MLP0_FUSED", "1") != "0"
+
+
+def mlp0_fused_supported(x2d, hidden):
+    return (MLP0_FUSED and x2d.dtype == torch.bfloat16 and x2d.is_cuda and x2d.dim() == 2 and x2d.shape[0] >= 4096
+            and bool(_lib.load().pswin_mlp0_bwd_supported(x2d.shape[1], hidden)) and fc1_gelu_supported(x2d, hidden)
+            and bool(_lib.load().pswin_gemm_skinny_supported(hidden, x2d.shape[1])))
+
+
+def mlp0_fused(x2d, fc1, fc2):
+    """fc2_nobias(gelu(fc1(x2d))) for the stage-0 Mlp as one autograd node: see _Mlp0."""
+    l1, l2 = fc1.__dict__.get("_lowp"), fc2.__dict__.get("_lowp")
+    return _Mlp0.apply(x2d, fc1.weight, fc1.bias, fc2.weight, l1[0] if l1 is not None else None, l2[0] if l2 is not None else None)
+
+
 def fc1_gelu_supported(x2d, n_out):
     return (x2d.dtype == torch.bfloat16 and x2d.is_cuda and x2d.shape[0] >= 4096
             and bool(_lib.load().pswin_fc1_gelu_supported(x2d.shape[1], n_out)))

@@ -923,6 +923,58 @@ def test_gemm_tn_ring_against_torch(ops, M, N, K, splits, out_bf16):
         assert torch.allclose(dbp[sp - 1], w_last, rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("M", [4096, 20000, 262144 + 48])
+def test_stage0_mlp_backward_in_one_pass(ops, M):
+    """pswin_mlp0_bwd: g = (dy W2) * gelu'(x W1^T + b1) and its column sums against fp32 torch on the same bf16 operands (ragged M:
+    rows past M must not enter the sums), then the autograd node ops.mlp0_fused against the two-node chain it replaces
+    (pswin_fc1_gelu_fwd/bwd + the fc2 Linear), whose dh is rounded to bf16 on its way through memory."""
+    import torch.nn as nn
+    from panoswintransformerobjectdetection_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(M)
+    C, Hd = 96, 384
+    assert lib.pswin_mlp0_bwd_supported(C, Hd) == 1 and lib.pswin_mlp0_bwd_supported(192, 768) == 0
+    fc1, fc2 = nn.Linear(C, Hd).to(DEV), nn.Linear(Hd, C).to(DEV)
+    x = torch.randn(M, C, device=DEV).to(torch.bfloat16)
+    dy = (torch.randn(M, C, device=DEV) * 0.1).to(torch.bfloat16)
+    w1b, w2b = fc1.weight.detach().to(torch.bfloat16).contiguous(), fc2.weight.detach().to(torch.bfloat16).contiguous()
+    b1 = fc1.bias.detach().float().contiguous()
+    rows = lib.pswin_mlp0_bwd_partial_rows(M)
+    assert 1 <= rows <= 256
+    g = torch.empty(M, Hd, dtype=torch.bfloat16, device=DEV)
+    ws = torch.empty(rows, Hd, dtype=torch.float32, device=DEV)
+    db = torch.empty(Hd, dtype=torch.float32, device=DEV)
+    ops.call("pswin_mlp0_bwd", x, ops.ptr(x), ops.ptr(w1b), ops.ptr(b1), ops.ptr(dy), ops.ptr(w2b), ops.ptr(g), ops.ptr(db), ops.ptr(ws), M, C, Hd)
+    pre = x.float() @ w1b.float().t() + b1
+    dh = dy.float() @ w2b.float()
+    cdf = 0.5 * (1 + torch.erf(pre / math.sqrt(2.0)))
+    want = dh * (cdf + pre * torch.exp(-0.5 * pre * pre) / math.sqrt(2 * math.pi))
+    scale = float(want.abs().max())
+    assert torch.allclose(g.float(), want, rtol=1e-2, atol=2e-3 * scale), float((g.float() - want).abs().max())
+    assert torch.allclose(ws.sum(0), db, rtol=1e-5, atol=1e-4)
+    assert torch.allclose(db, g.float().sum(0), rtol=2e-3, atol=2e-3 * float(g.float().abs().sum(0).max()))
+    g2 = torch.empty_like(g)                                                   # without column sums (workspace = NULL): the same rows
+    ops.call("pswin_mlp0_bwd", x, ops.ptr(x), ops.ptr(w1b), ops.ptr(b1), ops.ptr(dy), ops.ptr(w2b), ops.ptr(g2), None, None, M, C, Hd)
+    assert torch.equal(g2, g)
+    # the autograd node against the chain
+    for lin in (fc1, fc2):
+        lin.__dict__["_lowp"] = (lin.weight.detach().to(torch.bfloat16), lin.bias.detach().to(torch.bfloat16))
+    xa = x.clone().requires_grad_(True)
+    ya = ops.mlp0_fused(xa, fc1, fc2)
+    ya.backward(dy)
+    ga = [xa.grad.float(), fc1.weight.grad.clone(), fc1.bias.grad.clone(), fc2.weight.grad.clone()]
+    for p_ in (fc1.weight, fc1.bias, fc2.weight):
+        p_.grad = None
+    xb = x.clone().requires_grad_(True)
+    hb = ops.fc1_gelu(xb, fc1.weight, fc1.bias, fc1.__dict__["_lowp"][0])
+    yb = ops.linear(hb, fc2, torch.bfloat16, use_bias=False)
+    assert torch.equal(ya, yb)
+    yb.backward(dy)
+    gb = [xb.grad.float(), fc1.weight.grad, fc1.bias.grad, fc2.weight.grad]
+    for a_, b_ in zip(ga, gb):
+        assert torch.allclose(a_, b_, rtol=2e-2, atol=1e-2 * float(b_.abs().max())), float((a_ - b_).abs().max())
+
+
 @pytest.mark.parametrize("M,C,tile", [(16384, 384, 128), (4096, 768, 64), (333, 192, 64), (19600, 384, 128)])
 def test_gelu_backward_fused_into_the_fc2_data_gradient(ops, M, C, tile):
     """pswin_gemm_nt_gelu_bwd: (dy . W2) * gelu'(pre + b1) and the per-tile column sums, against fp32 torch on the same bf16
