@@ -69,7 +69,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md; ~6.3 TB
 MFMA_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 TIMED = ("pswin_win_attn_fused_fwd", "pswin_qkv_attn_fused_fwd", "pswin_attn_fwd", "pswin_attn_bwd", "pswin_attn_bwd_ex", "pswin_window_gather", "pswin_window_scatter_add",
          "pswin_scatter_add_ln_fwd", "pswin_ln_gather_fwd", "pswin_ln_gather_bwd", "pswin_bias_gelu_fwd", "pswin_bias_gelu_bwd",
-         "pswin_adamw_flat", "pswin_gemm_skinny", "pswin_gemm_nt", "pswin_gemm_nt_gelu_fwd", "pswin_gemm_nt_gelu_bwd", "pswin_gemm_tn", "pswin_gemm_tn_ring", "pswin_gemm_nt_ring", "pswin_roi_align_fwd", "pswin_roi_align_bwd", "pswin_fc1_gelu_fwd", "pswin_fc1_gelu_bwd", "pswin_mlp0_bwd", "pswin_stem_conv2_fwd", "pswin_stem_conv3_fwd",
+         "pswin_adamw_flat", "pswin_gemm_skinny", "pswin_gemm_nt", "pswin_gemm_nt_gelu_fwd", "pswin_gemm_nt_gelu_bwd", "pswin_gemm_tn", "pswin_gemm_tn_ring", "pswin_gemm_nt_ring", "pswin_roi_align_fwd", "pswin_roi_align_bwd", "pswin_fc1_gelu_fwd", "pswin_fc1_gelu_bwd", "pswin_mlp0_fwd", "pswin_mlp0_bwd", "pswin_stem_conv2_fwd", "pswin_stem_conv3_fwd",
          "pswin_stem_conv3_bwd_stats", "pswin_stem_conv3_bwd_data", "pswin_stem_conv3_wgrad", "pswin_stem_conv2_wgrad",
          "pswin_stem_conv2_bwd", "lib_gemm_fwd", "lib_gemm_dgrad", "lib_gemm_wgrad")
 # hardware MFMA-pipe utilisation of the window-attention kernels: SQ_VALU_MFMA_BUSY_CYCLES of a separate rocprofv3 --pmc pass

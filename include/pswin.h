@@ -416,6 +416,10 @@ int pswin_fc1_gelu_bwd(const void* x, const void* w, const float* bias, const vo
  * bf16; b1 f32 [hidden] or NULL; g [M, hidden] bf16; workspace f32 [pswin_mlp0_bwd_partial_rows(M)][hidden] receives the
  * per-workgroup column sums of g; dbias1 f32 [hidden] their fixed-order sum, or NULL (partial rows only); workspace = NULL: no column
  * sums (a caller that runs fc1's weight gradient on pswin_gemm_tn_ring_bias gets them from that launch).  C = 96, hidden = 384. */
+/* Stage-0 Mlp forward in one pass (HOT:50-58 without fc2's bias, which the caller adds with the residual): h[M, hidden] = gelu(x W1^T +
+ * b1) is written once for the backward pass and y[M, C] = h W2^T is formed from the first product's accumulators (h is not read
+ * back).  Same shapes and dtypes as pswin_mlp0_bwd; pswin_mlp0_bwd_supported(C, hidden) says whether both exist. */
+int pswin_mlp0_fwd(const void* x, const void* w1, const float* b1, const void* w2, void* h, void* y, long long M, int C, int hidden, void* stream);
 int pswin_mlp0_bwd_supported(int C, int hidden);
 int pswin_mlp0_bwd_partial_rows(long long M);
 int pswin_mlp0_bwd(const void* x, const void* w1, const float* b1, const void* dy, const void* w2, void* g, float* dbias1, float* workspace,

@@ -82,6 +82,7 @@ _PROTOTYPES = {
     "pswin_fc1_gelu_supported": [_i, _i],
     "pswin_fc1_gelu_fwd": [_vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _vp],
     "pswin_fc1_gelu_workspace": [_i],
+    "pswin_mlp0_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _vp],
     "pswin_mlp0_bwd_supported": [_i, _i],
     "pswin_mlp0_bwd_partial_rows": [ctypes.c_longlong],
     "pswin_mlp0_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _vp],

@@ -417,6 +417,127 @@ __global__ __launch_bounds__(M0_THREADS, 2) void mlp0_bwd_kernel(const void* __r
     }
 }
 
+// ---- stage-0 Mlp forward in one pass (round 3):  h = gelu(x W1^T + b1) (stored: the backward pass reads it), y = h W2^T ----------------
+// The second product takes h straight from the first one's accumulators: packing the two 16-column accumulator tiles of a 32-column
+// block gives the 32-deep B fragment in a permuted but fixed column order (slot 8 g + j = column 4 g + j for j < 4, 16 + 4 g + j - 4
+// otherwise -- the order pack8 / pswin_fused.hip use), and W2 is staged into LDS in that order, so h is written once and not read back
+// (201 MB per block at batch 8) and the fc2 launch is gone.  LDS: W1 image [384][192 B] + W2 image [96][768 B, chunk ^ (row & 15)].
+__global__ __launch_bounds__(M0_THREADS, 2) void mlp0_fwd_kernel(const void* __restrict__ x, const void* __restrict__ w1, const float* __restrict__ b1,
+                                                                 const void* __restrict__ w2, void* __restrict__ hout, void* __restrict__ yout, int M) {
+    constexpr int K = M0_K, N = M0_N, KS = M0_KS, OT = M0_K / 16;
+    auto woff = [](int row, int chunk) { return row * 192 + ((((chunk & ~3) | ((chunk ^ (row >> 1)) & 3))) << 4); };
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* w1l = smem;                                                    // [N][192]: W1 rows (hidden column n, contraction k)
+    char* w2l = smem + N * 192;                                          // [96][768]: W2 rows (output column o, contraction = hidden, permuted)
+    float* bl = reinterpret_cast<float*>(smem + 2 * N * 192);            // [N]
+    for (int i = threadIdx.x; i < N * (K / 8); i += M0_THREADS) {
+        const int row = i / (K / 8), ch = i - row * (K / 8);
+        *reinterpret_cast<u32x4*>(w1l + woff(row, ch)) = reinterpret_cast<const u32x4*>(w1)[i];
+    }
+    {
+        // fc2.weight [96][384]: 8-byte piece (o, block np, quad q = 0..7 of 4 columns) goes to chunk 4 np + (q & 3), half q >> 2
+        const unsigned long long* ws = reinterpret_cast<const unsigned long long*>(w2);
+        for (int i = threadIdx.x; i < K * (N / 4); i += M0_THREADS) {
+            const int o = i / (N / 4), q4 = i - o * (N / 4), np = q4 >> 3, qq = q4 & 7;
+            const int chunk = 4 * np + (qq & 3);
+            *reinterpret_cast<unsigned long long*>(w2l + o * 768 + ((chunk ^ (o & 15)) << 4) + 8 * (qq >> 2)) = ws[i];
+        }
+    }
+    for (int i = threadIdx.x; i < N; i += M0_THREADS) bl[i] = b1 ? b1[i] : 0.f;
+    __syncthreads();
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int c = lane & 15, g = lane >> 4;
+    const rsrc_t xs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(x), 0, (int)((size_t)M * K * 2), 0x00020000);
+    const rsrc_t hs = __builtin_amdgcn_make_buffer_rsrc(hout, 0, (int)((size_t)M * N * 2), 0x00020000);
+    const rsrc_t ys = __builtin_amdgcn_make_buffer_rsrc(yout, 0, (int)((size_t)M * K * 2), 0x00020000);
+    const int ntiles = (M + 15) / 16;
+    const int d0 = 8 * (g >> 1) + 16 * (g & 1);
+    const int lane_off = c * 192 + (((g ^ (c >> 1)) & 3) << 4);
+    // W2 fragment (output tile ot, block np): row 16 ot + c, chunk (4 np + g) ^ c = 16 (np >> 2) + ((4 (np & 3) + g) ^ c)
+    const char* w2b[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w2b[j] = w2l + c * 768 + (((4 * j + g) ^ c) << 4);
+    bf16x8 bx[KS];
+    auto load_b = [&](int tile) {
+        const unsigned row = (unsigned)tile * 16 + c;
+        const unsigned off = row < (unsigned)M ? row * (unsigned)(K * 2) + 16u * g : 0xFFFFFF00u;          // rows >= M: zeros
+#pragma unroll
+        for (int s = 0; s < KS; ++s) bx[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(xs, off == 0xFFFFFF00u ? off : off + 64u * s, 0, 0));
+    };
+    const int tile0 = blockIdx.x * M0_WAVES + wave, tstep = gridDim.x * M0_WAVES;
+    auto row_tile = [&](int tile) {
+        const unsigned row = (unsigned)tile * 16 + c;
+        const unsigned hbase = row < (unsigned)M ? row * (unsigned)(N * 2) + 2u * d0 : 0xFFFFFF00u;
+        const unsigned ybase = row < (unsigned)M ? row * (unsigned)(K * 2) + 2u * d0 : 0xFFFFFF00u;
+        int zb = 0;                                                      // (keeps the bias reads in the epilogue: see mlp0_bwd_kernel)
+        asm volatile("" : "+v"(zb));
+        const float* blt = bl + zb;
+        f32x4 ay[OT];
+#pragma unroll
+        for (int ot = 0; ot < OT; ++ot) ay[ot] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            f32x4 ap[M0_HT];
+#pragma unroll
+            for (int t = 0; t < M0_HT; ++t) ap[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const char* img1 = w1l + lane_off + half * (M0_HT * 3072);
+            constexpr int BT = 6, BPS = M0_HT / BT, NB = KS * BPS;
+            bf16x8 a[2][BT];
+            auto read_batch = [&](int bi, bf16x8 (&dst)[BT]) {
+                const int s_ = bi / BPS, e0 = (bi - s_ * BPS) * BT;
+#pragma unroll
+                for (int j = 0; j < BT; ++j) dst[j] = *reinterpret_cast<const bf16x8*>(img1 + 3072 * (e0 + j) + 64 * s_);
+            };
+            read_batch(0, a[0]);
+#pragma unroll
+            for (int bi = 0; bi < NB; ++bi) {
+                if (bi + 1 < NB) read_batch(bi + 1, a[(bi + 1) & 1]);
+                const int s_ = bi / BPS, e0 = (bi - s_ * BPS) * BT;
+#pragma unroll
+                for (int j = 0; j < BT; ++j) ap[e0 + j] = mfma32(a[bi & 1][j], bx[s_], ap[e0 + j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (half == 1 && tile + tstep < ntiles) load_b(tile + tstep);       // next tile's rows before this half's stores
+            __builtin_amdgcn_sched_barrier(0);
+            // one 32-column block at a time: bias + GELU, the bf16 fragment, its 6 products into y, the h store
+#pragma unroll
+            for (int np = 0; np < M0_HT / 2; ++np) {
+                const int blk = 6 * half + np, col = 32 * blk;
+                bf16x8 w2f[OT];
+#pragma unroll
+                for (int ot = 0; ot < OT; ++ot) w2f[ot] = *reinterpret_cast<const bf16x8*>(w2b[blk & 3] + 16 * ot * 768 + (blk >> 2) * 256);
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(blt + col + 4 * g);
+                const f32x4 b1v = *reinterpret_cast<const f32x4*>(blt + col + 16 + 4 * g);
+                f32x4 q0 = ap[2 * np] + b0, q1 = ap[2 * np + 1] + b1v;
+#pragma unroll
+                for (int e = 0; e < 4; e += 2) {
+                    const gelu_f32x2 h0 = gelu_f2(gelu_f32x2{q0[e], q0[e + 1]}), h1 = gelu_f2(gelu_f32x2{q1[e], q1[e + 1]});
+                    q0[e] = h0[0]; q0[e + 1] = h0[1];
+                    q1[e] = h1[0]; q1[e + 1] = h1[1];
+                }
+                unsigned a0 = pack_bf16(q0[0], q0[1]), a1 = pack_bf16(q0[2], q0[3]), c0 = pack_bf16(q1[0], q1[1]), c1 = pack_bf16(q1[2], q1[3]);
+                const bf16x8 hf = __builtin_bit_cast(bf16x8, u32x4{a0, a1, c0, c1});
+#pragma unroll
+                for (int ot = 0; ot < OT; ++ot) ay[ot] = mfma32(w2f[ot], hf, ay[ot]);
+                swap16_u32(a0, c0);
+                swap16_u32(a1, c1);
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{a0, a1, c0, c1}, hs, hbase == 0xFFFFFF00u ? hbase : hbase + 2u * col, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ay[ot][e] = y[row c][column 16 ot + 4 g + e]
+#pragma unroll
+        for (int p2 = 0; p2 < OT / 2; ++p2)
+            __builtin_amdgcn_raw_buffer_store_b128(pack_row8(ay[2 * p2], ay[2 * p2 + 1]), ys, ybase == 0xFFFFFF00u ? ybase : ybase + 64u * p2, 0, 0);
+    };
+    if (tile0 < ntiles) {
+        load_b(tile0);
+        row_tile(tile0);
+        for (int tile = tile0 + tstep; tile < ntiles; tile += tstep) row_tile(tile);
+    }
+}
+
 constexpr int M0_MAX_GRID = 256;                 // one 8-wave workgroup per CU (147 KB of weights in LDS)
 inline int mlp0_grid(long long M) {
     const long long ntiles = (M + 15) / 16, g = (ntiles + M0_WAVES - 1) / M0_WAVES;
@@ -496,6 +617,18 @@ int pswin_mlp0_bwd(const void* x, const void* w1, const float* b1, const void* d
         if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&mlp0_bwd_kernel<false>), M0_LDS, configured)) return rc;
         hipLaunchKernelGGL(mlp0_bwd_kernel<false>, dim3(grid), dim3(M0_THREADS), M0_LDS, st, x, w1, b1, dy, w2, g, workspace, (int)M);
     }
+    PSWIN_LAUNCH_RET();
+}
+
+/* Stage-0 Mlp forward in one pass (HOT:50-58 without fc2's bias): h[M, hidden] = gelu(x W1^T + b1) (kept for the backward pass),
+ * y[M, C] = h W2^T from the accumulators of the first product.  x [M, C] bf16; w1 [hidden, C], w2 [C, hidden] bf16; b1 f32 or NULL. */
+int pswin_mlp0_fwd(const void* x, const void* w1, const float* b1, const void* w2, void* h, void* y, long long M, int C, int hidden, void* stream) {
+    PSWIN_CHECK_ARG(x && w1 && w2 && h && y && M > 0 && pswin_mlp0_bwd_supported(C, hidden));
+    PSWIN_CHECK_ARG(M * (long long)hidden * 2 < 0xFFFFFF00ll && aligned16(x) && aligned16(w1) && aligned16(w2) && aligned16(h) && aligned16(y));
+    constexpr int lds = 2 * M0_N * 192 + M0_N * 4;
+    static std::atomic<unsigned long long> configured{0};
+    if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&mlp0_fwd_kernel), lds, configured)) return rc;
+    hipLaunchKernelGGL(mlp0_fwd_kernel, dim3(mlp0_grid(M)), dim3(M0_THREADS), lds, (hipStream_t)stream, x, w1, b1, w2, h, y, (int)M);
     PSWIN_LAUNCH_RET();
 }
 

@@ -968,8 +968,13 @@ class _Mlp0(torch.autograd.Function):
         N = w1b.shape[0]
         h = torch.empty(M, N, dtype=x.dtype, device=x.device)
         b = b1.detach().float().contiguous()
-        call("pswin_fc1_gelu_fwd", x, ptr(x), ptr(w1b), ptr(b), ptr(h), M, K, N, algo_bytes=2 * M * (K + N))
-        y = skinny_gemm(h, w2b, None)
+        if MLP0_FUSED_FWD:                                   # both products in one pass: h is written once and not read back
+            y = torch.empty(M, K, dtype=x.dtype, device=x.device)
+            call("pswin_mlp0_fwd", x, ptr(x), ptr(w1b), ptr(b), ptr(w2b), ptr(h), ptr(y), M, K, N,
+                 algo_bytes=2 * M * (2 * K + N), algo_flops=4 * M * K * N)
+        else:
+            call("pswin_fc1_gelu_fwd", x, ptr(x), ptr(w1b), ptr(b), ptr(h), M, K, N, algo_bytes=2 * M * (K + N))
+            y = skinny_gemm(h, w2b, None)
         ctx.save_for_backward(x, w1b, b, h, w2b)
         ctx.params = (w1, b1, w2)
         return y
@@ -1001,6 +1006,8 @@ class _Mlp0(torch.autograd.Function):
 
 # PSWIN_MLP0_FUSED=0: the stage-0 Mlp as fc1 + GELU node and fc2 node (library data gradient, pswin_fc1_gelu_bwd) -- A/B
 MLP0_FUSED = os.environ.get("PSWIN_MLP0_FUSED", "1") != "0"
+# PSWIN_MLP0_FUSED_FWD=0: its forward as pswin_fc1_gelu_fwd + the streaming GEMM for fc2 -- A/B
+MLP0_FUSED_FWD = os.environ.get("PSWIN_MLP0_FUSED_FWD", "1") != "0"
 
 
 def mlp0_fused_supported(x2d, hidden):
