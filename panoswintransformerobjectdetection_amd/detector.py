@@ -72,6 +72,16 @@ def decode_deltas(src, deltas, stds, max_shape):
     return torch.stack([(x - w * 0.5).clamp(0, W), (y - h * 0.5).clamp(0, H), (x + w * 0.5).clamp(0, W), (y + h * 0.5).clamp(0, H)], 1)
 
 
+def _topk_stable(scores, k):
+    """The k largest scores and their indices, ties broken by index (stable sort).  torch.topk picks among EQUAL scores in an order
+    that depends on the timing of its atomics: with bf16 RPN logits (thousands of exactly equal values at initialisation) two passes
+    over bit-identical feature maps then keep different proposals -- same losses to six digits, feature-map gradients 11 % apart
+    (seen between replays of one captured step).  mmdet's own top-k has the same property; a stand-in that is replayed from a hipGraph
+    and compared with an eager step should not."""
+    s, i = torch.sort(scores, descending=True, stable=True)
+    return s[:k], i[:k]
+
+
 def nms_keep(boxes, iou_thr, iters=12):
     """Greedy NMS on score-sorted boxes as a fixed point: keep[j] = not any(i < j: keep[i] and IoU(i, j) > thr).  Starting
     from "keep all", every sweep fixes at least one more level of the suppression chains; `iters` sweeps of one [n, n]
@@ -251,14 +261,14 @@ class MiniMaskRCNN(nn.Module):
                     n = a_l.shape[0]
                     sc = cls_all[b, at:at + n]
                     k = min(cfg["nms_pre"], n)
-                    top, ti = sc.topk(k)
+                    top, ti = _topk_stable(sc, k)
                     bx = decode_deltas(a_l[ti], reg_all[b, at:at + n][ti], (1.0, 1.0, 1.0, 1.0), img_hw)
                     keep = nms_keep(bx, cfg["nms"])
                     boxes_l.append(bx)
                     scores_l.append(torch.where(keep, top, top.new_full((), -1e4)))
                     at += n
                 bx, sc = torch.cat(boxes_l), torch.cat(scores_l)
-                ti = sc.topk(min(cfg["max_per_img"], sc.numel()))[1]
+                ti = _topk_stable(sc, min(cfg["max_per_img"], sc.numel()))[1]
                 proposals.append(bx[ti])
         return loss_cls / B, loss_reg / B, proposals
 

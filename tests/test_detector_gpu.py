@@ -79,7 +79,8 @@ def test_configs2_workload_panoswin_t_512x1024_step_and_its_hipgraph_arrangement
     every parameter of the backbone and of every head reached by a finite gradient; (2) the hand-off bench.py --config maskrcnn
     uses -- backbone forward | heads on detached maps | backbone backward fed with the heads' feature-map gradients -- reproduces
     the end-to-end backbone gradients; (3) that arrangement captured as THREE hipGraphs sharing a memory pool (what the bench
-    replays) gives the same losses and backbone gradients as the eager step, first and later replays."""
+    replays) gives the same losses as the eager step and backbone gradients equal to an eager backward pass fed with the replay's own
+    feature-map gradients, first and later replays."""
     # Everything -- parameter allocation, the eager passes, warm-up, capture, replay -- runs on ONE side stream, as in bench.py: autograd's
     # AccumulateGrad nodes remember the stream of the first backward pass, and nodes created on the default stream make a later capture
     # on another stream synchronise with it (torch warns "may break CUDA graph capture"; here hipStreamEndCapture then crashes).
@@ -177,11 +178,22 @@ def _configs2_body(side):
                 # same samples (fixed keys); RoIAlign's backward and torch's index / scatter backward passes add with atomics, and the
                 # heads' weights are untouched between replays: losses agree to rounding
                 assert abs(got[k] - v) <= 2e-3 * max(abs(v), 1e-3), (replay, k, got[k], v)
-            for g, want in zip(gbuf, G):
-                assert rel(g, want) < 2e-2, (replay, rel(g, want))
-            werr = max((rel(p.grad, ref["backbone." + k]), k) for k, p in bb.named_parameters() if not any(z in k for z in ZERO_GRAD_KEYS))
-            record(f"configs2_graph_replay{replay}", worst_rel=werr[0], key=werr[1])
-            assert werr[0] < 5e-2, (replay, werr)       # through gbuf (atomics-ordered sums in the heads), not bitwise
+            # The head stand-ins are NOT run-to-run deterministic on identical feature maps (tools/debug_heads_determinism.py: MIOpen's
+            # bf16 convolutions differ in the last bit between calls, and with freshly initialised RPN / box heads thousands of scores
+            # are within that bit, so a few of the 2 x 512 sampled RoIs change from call to call: the classification loss moves in its
+            # sixth digit, its feature-map gradient by ~12 % in norm).  So the heads' gradients of a replay are compared with the eager
+            # step's only loosely; what the ARRANGEMENT has to guarantee is checked exactly: the backbone's captured backward pass, fed
+            # with whatever feature-map gradients this replay's heads produced, equals an eager backward pass fed with the same ones.
+            head_rel = [rel(g, want) for g, want in zip(gbuf, G)]
+            assert all(bool(torch.isfinite(g).all()) for g in gbuf) and max(head_rel) < 0.5, (replay, head_rel)
+            got_grads = {k: p.grad.detach().clone() for k, p in bb.named_parameters()}
+            fed = [g.clone() for g in gbuf]
+            red.zero_grad()
+            torch.autograd.backward(bb(x), fed)
+            red.pack_grads()
+            werr = max((rel(got_grads[k], p.grad), k) for k, p in bb.named_parameters() if not any(z in k for z in ZERO_GRAD_KEYS))
+            record(f"configs2_graph_replay{replay}", worst_rel=werr[0], key=werr[1], heads_vs_eager_rel=max(head_rel))
+            assert werr[0] < 1e-5, (replay, werr)
             assert all(bool(torch.isfinite(p.grad).all()) for p in heads)
     finally:
         _ops.set_deferred_reductions(prev)
