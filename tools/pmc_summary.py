@@ -22,7 +22,10 @@ KERNELS = {"win_fused_fwd_kernel": "pswin_win_attn_fused_fwd", "attn_fwd_kernel"
            # the tiled GEMM by epilogue (template arguments <rows, EPI>): plain, fused GELU backward, fused GELU forward
            "gemm_nt_kernel<64, 0>": "pswin_gemm_nt", "gemm_nt_kernel<128, 0>": "pswin_gemm_nt",
            "gemm_nt_kernel<64, 1>": "pswin_gemm_nt_gelu_bwd", "gemm_nt_kernel<128, 1>": "pswin_gemm_nt_gelu_bwd",
-           "gemm_nt_kernel<64, 2>": "pswin_gemm_nt_gelu_fwd", "gemm_nt_kernel<128, 2>": "pswin_gemm_nt_gelu_fwd"}
+           "gemm_nt_kernel<64, 2>": "pswin_gemm_nt_gelu_fwd", "gemm_nt_kernel<128, 2>": "pswin_gemm_nt_gelu_fwd",
+           # round 3
+           "gemm_tn_ring_kernel": "pswin_gemm_tn_ring", "qkv_attn_fwd_kernel": "pswin_qkv_attn_fused_fwd", "mlp0_fwd_kernel": "pswin_mlp0_fwd",
+           "mlp0_bwd_kernel": "pswin_mlp0_bwd", "skinny_gemm_kernel": "pswin_gemm_skinny"}
 
 
 def collect(path, counter):
@@ -30,14 +33,16 @@ def collect(path, counter):
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
-        for key, name in KERNELS.items():
-            if key in r["Kernel_Name"]:
-                acc[name][0] += float(r["Counter_Value"]) * 1024.0
-                acc[name][1] += 1
+        hits = [key for key in KERNELS if key in r["Kernel_Name"]]
+        if hits:                                     # the longest key wins (qkv_attn_fwd_kernel contains attn_fwd_kernel)
+            name = KERNELS[max(hits, key=len)]
+            acc[name][0] += float(r["Counter_Value"]) * 1024.0
+            acc[name][1] += 1
     return acc
 
 
-FETCH_FACTOR = {"pswin_attn_fwd": 1.0, "pswin_attn_bwd_ex": 1.0, "pswin_win_attn_fused_fwd": 2.0}      # calibrated (see above); default 2.0 (wide row reads)
+FETCH_FACTOR = {"pswin_attn_fwd": 1.0, "pswin_attn_bwd_ex": 1.0, "pswin_win_attn_fused_fwd": 2.0,      # calibrated (see above); default 2.0 (wide row reads)
+                "pswin_qkv_attn_fused_fwd": 1.0}                                                            # 64-byte segments of a row per instruction, as the attention kernels
 fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
 out = {}
 for name in sorted(set(fetch) | set(write)):
