@@ -56,16 +56,18 @@ def test_roi_align_forward_matches_the_definition(ops, dtype, P, C):
         assert torch.allclose(a.float(), b.float(), rtol=tol, atol=tol)
 
 
-@pytest.mark.parametrize("dtype,P", [(torch.float32, 7), (torch.bfloat16, 14)])
-def test_roi_align_backward_is_the_adjoint(ops, dtype, P):
+@pytest.mark.parametrize("dtype,P,sr", [(torch.float32, 7, 0), (torch.bfloat16, 14, 0), (torch.float32, 7, 2), (torch.float32, 2, 0)])
+def test_roi_align_backward_is_the_adjoint(ops, dtype, P, sr):
+    """one atomic per touched cell (separable row / column weights) for footprints up to 16 x 16 cells, the per-sample path beyond
+    (P = 2 on 400-pixel boxes at stride 4 .. 8; fixed 2 x 2 grids over large bins: samples further than a cell apart)"""
     B, H, W, C = 2, 128, 256, 256
     feats = [f.requires_grad_(True) for f in _pyramid(B, C, H, W, dtype, 3)]
     rois = _rois(B, H, W, 64, 4)
     w = torch.randn(64, C, P, P, device=DEV)
-    (ops.roi_align_fpn(feats, STRIDES, rois, P).float() * w).sum().backward()
+    (ops.roi_align_fpn(feats, STRIDES, rois, P, sampling_ratio=sr).float() * w).sum().backward()
     got = [f.grad.float().clone() for f in feats]
     ref_feats = [f.detach().float().requires_grad_(True) for f in feats]
-    (_roi_ref.roi_align_fpn(ref_feats, STRIDES, rois, P) * (w.to(dtype).float() if dtype != torch.float32 else w)).sum().backward()
+    (_roi_ref.roi_align_fpn(ref_feats, STRIDES, rois, P, sampling_ratio=sr) * (w.to(dtype).float() if dtype != torch.float32 else w)).sum().backward()
     used = set(_roi_ref.map_roi_levels(rois, 4).tolist())
     assert len(used) >= 3
     for l, (g, r) in enumerate(zip(got, ref_feats)):
