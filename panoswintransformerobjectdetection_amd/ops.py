@@ -67,7 +67,9 @@ def set_deferred_reductions(on):
     already holds a ``.grad`` (autograd would accumulate into it at once), carries a tensor / post-accumulate hook
     (dp.GradReducer(pack=False) launches its all-reduce from one), or already received a postponed gradient in the same
     pass (a module applied twice: autograd adds the two as soon as the second arrives; the queue is flushed first).
-    Returns the previous setting."""
+    NOT covered: hooks registered on a parameter's AccumulateGrad NODE (torch DistributedDataParallel's reducer,
+    ``grad_fn.register_hook`` consumers) are invisible from Python and would read unfilled gradients -- use dp.GradReducer (which
+    this mode is built for) or leave deferral off under DDP.  Returns the previous setting."""
     prev, _ReduceQueue.enabled = _ReduceQueue.enabled, bool(on)
     return prev
 
@@ -141,6 +143,17 @@ def _deferring(owners=()):
         return None
     q["owners"].update(keys)
     return q
+
+
+def flush_if_pending(owners=()):
+    """A gradient of `owners` is about to be returned to autograd WITHOUT going through the queue (a weight gradient small enough
+    for one launch): if an earlier use of the same parameter in this pass left a postponed (still unfilled) gradient in the queue,
+    autograd would add the two at once -- issue the queue first.  (A module applied to one large and one small input.)"""
+    if not _ReduceQueue.enabled:
+        return
+    q = _ReduceQueue.tasks.get(torch._C._current_graph_task_id())
+    if q is not None and any(o is not None and o.data_ptr() in q["owners"] for o in owners):
+        _launch_queue(q)
 
 
 def grad_slot(param):
@@ -882,8 +895,10 @@ def linear_backward(x, wb, dy, weight, bias, zero_bias_cols, need_dx, wbt=None):
                 dw = (dy.t() @ x).float()
     if ch > 1:
         dw = sum_rows(part, ch, N * K, out=grad_slot(weight), owners=(weight,)).view(N, K)
-    elif sp:
-        dw = part.view(N, K).float()
+    else:
+        if sp:
+            dw = part.view(N, K).float()
+        flush_if_pending((weight,))                          # an immediate gradient behind a postponed one of the same weight
     if db_part is not None:
         db = sum_rows(db_part, db_part.shape[0], N, owners=(bias,))
     else:
@@ -951,6 +966,8 @@ class _Fc1Gelu(torch.autograd.Function):
                     dw = (dy.t() @ x).float()
         if ch > 1:
             dw = sum_rows(part, ch, N * K, out=grad_slot(ctx.weight), owners=(ctx.weight,)).view(N, K)
+        else:
+            flush_if_pending((ctx.weight,))
         return dx, dw, db, None
 
 

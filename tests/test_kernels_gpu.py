@@ -923,6 +923,37 @@ def test_gemm_tn_ring_against_torch(ops, M, N, K, splits, out_bf16):
         assert torch.allclose(dbp[sp - 1], w_last, rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("large_first", [False, True])
+def test_deferred_reductions_with_a_linear_applied_to_a_large_and_a_small_input(ops, large_first):
+    """One nn.Linear used twice in a pass, once on enough rows for a split weight gradient (postponed to the end of the pass) and once
+    on a handful (one launch, returned to autograd at once): whichever comes second, autograd must never add an unfilled tensor
+    (the immediate path behind a postponed gradient of the same weight)."""
+    import torch.nn as nn
+    torch.manual_seed(5)
+    lin = nn.Linear(192, 192).to(DEV)
+    lin.__dict__["_lowp"] = (lin.weight.detach().to(torch.bfloat16), lin.bias.detach().to(torch.bfloat16))
+    xl = torch.randn(8192, 192, device=DEV).to(torch.bfloat16)
+    xs = torch.randn(64, 192, device=DEV).to(torch.bfloat16)
+
+    def run():
+        lin.weight.grad = lin.bias.grad = None
+        a, b = (xl, xs) if large_first else (xs, xl)
+        y = ops.linear(a, lin, torch.bfloat16).float().sum() + 2.0 * ops.linear(b, lin, torch.bfloat16).float().sum()
+        y.backward()
+        torch.cuda.synchronize()
+        return lin.weight.grad.clone(), lin.bias.grad.clone()
+
+    want = run()
+    prev = ops.set_deferred_reductions(True)
+    try:
+        got = run()
+    finally:
+        ops.set_deferred_reductions(prev)
+    for g, w in zip(got, want):
+        assert torch.isfinite(g).all()
+        assert torch.allclose(g, w, rtol=1e-3, atol=1e-3 * float(w.abs().max())), float((g - w).abs().max())
+
+
 @pytest.mark.parametrize("M", [4096, 20000, 262144 + 48])
 def test_stage0_mlp_backward_in_one_pass(ops, M):
     """pswin_mlp0_bwd: g = (dy W2) * gelu'(x W1^T + b1) and its column sums against fp32 torch on the same bf16 operands (ragged M:
