@@ -129,7 +129,10 @@ __global__ void stem_pack_kernel(const float* __restrict__ x, long long npix_per
 // F3: tokens = conv3(relu(bn2(y2))) + bias     (4x4 stride 4: one GEMM row per token, K = 16 taps x 64 channels)
 // ---------------------------------------------------------------------------------------------
 constexpr int W3S_BYTES = C3 * 128;          // one tap slice [96 out][64 in]
-constexpr int TOK_WG = TNW * 16;              // 128 tokens per workgroup
+constexpr int TOK_WG = TNW * 16;              // 128 tokens per workgroup and token tile
+#ifndef PSWIN_STEM_CONV3_TT
+#define PSWIN_STEM_CONV3_TT 4                 // token tiles per wave in the conv3 forward kernel (A/B builds: 1, 2)
+#endif
 
 struct TokGeo {
     long long pix;       // pixel index of the token's top-left pixel in [B][H][W]
@@ -153,6 +156,11 @@ __device__ inline bf16x8 bn_relu8(u32x4 raw, const float (&sc)[8], const float (
     return __builtin_bit_cast(bf16x8, o);
 }
 
+// TT token tiles (16 tokens each) per wave and weight stage: a tap's 12 KB weight slice is staged once per TT * 128 tokens of the
+// workgroup and every weight fragment read from LDS feeds TT MFMAs.  With TT = 1 (the first version) a wave had ONE tile: 12 LDS
+// fragment reads for 12 MFMAs (twice what the LDS pipe delivers under a busy matrix pipe), a barrier and an exposed memory round trip
+// per tap and 128 tokens -- 175 us for a pass whose traffic takes 93.
+template <int TT>
 __global__ __launch_bounds__(TWG) void stem_conv3_fwd_kernel(const void* __restrict__ y2, const float* __restrict__ scale2,
                                                             const float* __restrict__ shift2, const void* __restrict__ w3p,
                                                             const float* __restrict__ bias3, int H, int W, long long M,
@@ -161,15 +169,22 @@ __global__ __launch_bounds__(TWG) void stem_conv3_fwd_kernel(const void* __restr
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int c = lane & 15, g = lane >> 4;
     const int Hh = H / 4, Wh = W / 4;
-    const long long tok_wg = (long long)blockIdx.x * TOK_WG;
-    long long tok = tok_wg + wave * 16 + c;
-    const bool valid = tok < M;
-    if (!valid) tok = M - 1;
+    const long long tok_wg = (long long)blockIdx.x * (TOK_WG * TT);
+    // tile t of this wave: tokens tok_wg + (TT * wave + t) * 16 + c
+    long long tok[TT];
+    bool valid[TT];
     const long long base_pix = token_pix(tok_wg, Hh, Wh, H, W);                 // uniform
     const long long rem_bytes = y2_bytes - base_pix * 128;
     const rsrc_t ys = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(y2)) + base_pix * 128, 0,
                                                         (int)(rem_bytes > 0xFFFFFFFFll ? 0xFFFFFFFFll : rem_bytes), 0x00020000);
-    const unsigned voff = (unsigned)((token_pix(tok, Hh, Wh, H, W) - base_pix) * 128) + 16u * g;
+    unsigned voff[TT];
+#pragma unroll
+    for (int t = 0; t < TT; ++t) {
+        tok[t] = tok_wg + (TT * wave + t) * 16 + c;
+        valid[t] = tok[t] < M;
+        if (!valid[t]) tok[t] = M - 1;
+        voff[t] = (unsigned)((token_pix(tok[t], Hh, Wh, H, W) - base_pix) * 128) + 16u * g;
+    }
     float sc[2][8], sh[2][8];
 #pragma unroll
     for (int s = 0; s < 2; ++s)
@@ -192,12 +207,17 @@ __global__ __launch_bounds__(TWG) void stem_conv3_fwd_kernel(const void* __restr
     u32x4 r0, r1 = {0u, 0u, 0u, 0u};
     stage_load(0, r0, r1);
     stage_store(0, r0, r1);
-    u32x4 yb[2], yn[2];
-    yb[0] = __builtin_amdgcn_raw_buffer_load_b128(ys, voff, 0, 0);
-    yb[1] = __builtin_amdgcn_raw_buffer_load_b128(ys, voff + 64u, 0, 0);
-    f32x4 acc[6];
+    u32x4 yb[TT][2], yn[TT][2];
 #pragma unroll
-    for (int mt = 0; mt < 6; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < TT; ++t) {
+        yb[t][0] = __builtin_amdgcn_raw_buffer_load_b128(ys, voff[t], 0, 0);
+        yb[t][1] = __builtin_amdgcn_raw_buffer_load_b128(ys, voff[t] + 64u, 0, 0);
+    }
+    f32x4 acc[TT][6];
+#pragma unroll
+    for (int t = 0; t < TT; ++t)
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt) acc[t][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
     __syncthreads();
     for (int tap = 0; tap < 16; ++tap) {
         const int buf = tap & 1;
@@ -205,35 +225,52 @@ __global__ __launch_bounds__(TWG) void stem_conv3_fwd_kernel(const void* __restr
             stage_load(tap + 1, r0, r1);
             const int nt = tap + 1;
             const int soff = ((nt >> 2) * W + (nt & 3)) * 128;
-            yn[0] = __builtin_amdgcn_raw_buffer_load_b128(ys, voff, soff, 0);
-            yn[1] = __builtin_amdgcn_raw_buffer_load_b128(ys, voff + 64u, soff, 0);
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+                yn[t][0] = __builtin_amdgcn_raw_buffer_load_b128(ys, voff[t], soff, 0);
+                yn[t][1] = __builtin_amdgcn_raw_buffer_load_b128(ys, voff[t] + 64u, soff, 0);
+            }
         }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const bf16x8 b = bn_relu8(yb[s], sc[s], sh[s]);
+            bf16x8 b[TT];
+#pragma unroll
+            for (int t = 0; t < TT; ++t) b[t] = bn_relu8(yb[t][s], sc[s], sh[s]);
 #pragma unroll
             for (int mt = 0; mt < 6; ++mt) {
                 const bf16x8 a = *reinterpret_cast<const bf16x8*>(w3s[buf] + off128(16 * mt + c, 4 * s + g));
-                acc[mt] = mfma32(a, b, acc[mt]);
+#pragma unroll
+                for (int t = 0; t < TT; ++t) acc[t][mt] = mfma32(a, b[t], acc[t][mt]);
             }
         }
         if (tap + 1 < 16) {
             stage_store(buf ^ 1, r0, r1);
-            yb[0] = yn[0];
-            yb[1] = yn[1];
+#pragma unroll
+            for (int t = 0; t < TT; ++t) {
+                yb[t][0] = yn[t][0];
+                yb[t][1] = yn[t][1];
+            }
         }
         __syncthreads();
     }
     // + bias, bf16, 8 consecutive channels per lane
+    float bv[6][4];
 #pragma unroll
     for (int mt = 0; mt < 6; ++mt)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) acc[mt][e] += bias3[16 * mt + 4 * g + e];
-    char* dst = reinterpret_cast<char*>(tok_out) + tok * (C3 * 2) + row8_d0(g) * 2;
+        for (int e = 0; e < 4; ++e) bv[mt][e] = bias3[16 * mt + 4 * g + e];
 #pragma unroll
-    for (int pr = 0; pr < 3; ++pr) {
-        const u32x4 v = pack_row8(g, acc[2 * pr], acc[2 * pr + 1]);
-        if (valid) *reinterpret_cast<u32x4*>(dst + pr * 64) = v;
+    for (int t = 0; t < TT; ++t) {
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[t][mt][e] += bv[mt][e];
+        char* dst = reinterpret_cast<char*>(tok_out) + tok[t] * (C3 * 2) + row8_d0(g) * 2;
+#pragma unroll
+        for (int pr = 0; pr < 3; ++pr) {
+            const u32x4 v = pack_row8(g, acc[t][2 * pr], acc[t][2 * pr + 1]);
+            if (valid[t]) *reinterpret_cast<u32x4*>(dst + pr * 64) = v;
+        }
     }
 }
 
@@ -698,8 +735,9 @@ int pswin_stem_conv3_fwd(const void* y2, const float* scale2, const float* shift
                          int B, int H, int W, void* tokens, void* stream) {
     PSWIN_CHECK_ARG(y2 && scale2 && shift2 && w3p && bias3 && tokens && B > 0 && H > 0 && W > 0 && H % 4 == 0 && W % 4 == 0);
     const long long M = (long long)B * (H / 4) * (W / 4);
-    const unsigned grid = (unsigned)((M + TOK_WG - 1) / TOK_WG);
-    hipLaunchKernelGGL(stem_conv3_fwd_kernel, dim3(grid), dim3(TWG), 0, (hipStream_t)stream, y2, scale2, shift2, w3p, bias3, H,
+    constexpr int TT = PSWIN_STEM_CONV3_TT;
+    const unsigned grid = (unsigned)((M + TOK_WG * TT - 1) / (TOK_WG * TT));
+    hipLaunchKernelGGL(stem_conv3_fwd_kernel<TT>, dim3(grid), dim3(TWG), 0, (hipStream_t)stream, y2, scale2, shift2, w3p, bias3, H,
                        W, M, (long long)B * H * W * 128, tokens);
     PSWIN_LAUNCH_RET();
 }
