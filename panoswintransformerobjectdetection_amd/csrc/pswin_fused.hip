@@ -245,11 +245,8 @@ __global__ __launch_bounds__(FTHREADS, 2) void win_fused_fwd_kernel(FusedArgs a)
                 __builtin_amdgcn_sched_barrier(0);
                 gemm_T(wB, bB, kf);                   // K^T
                 __builtin_amdgcn_sched_barrier(0);
+                [[maybe_unused]] rsrc_t vs_save;
                 if constexpr (SAVE) {
-                    // rows for the backward pass: V^T in the token-on-lane orientation as well (24 more MFMAs; the matrix
-                    // pipe has the room, an LDS transpose of the other orientation costs VALU / LDS issue slots instead)
-                    u32x4 vf[4];
-                    gemm_T(wA, bA, vf);
                     // q, k, v of (window, head) as three contiguous [49][32] blocks ([n][heads][3][49][32], the packing
                     // pswin_attn_bwd_ex reads): a store instruction then writes ONE 1 KB run (16 tokens x 64 B) instead of 16
                     // 64-byte segments 576 B apart; tokens >= 49 fall outside the resource and are dropped
@@ -258,14 +255,13 @@ __global__ __launch_bounds__(FTHREADS, 2) void win_fused_fwd_kernel(FusedArgs a)
                                                                         BLK, 0x00020000);
                     const rsrc_t ks = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.qkv) + (win * FH + h) * (size_t)(3 * BLK) + BLK, 0,
                                                                         BLK, 0x00020000);
-                    const rsrc_t vs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.qkv) + (win * FH + h) * (size_t)(3 * BLK) + 2 * BLK,
-                                                                        0, BLK, 0x00020000);
+                    vs_save = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(a.qkv) + (win * FH + h) * (size_t)(3 * BLK) + 2 * BLK, 0, BLK,
+                                                                0x00020000);
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         const unsigned ro = (unsigned)((16 * t + c) * (HD * 2) + d0 * 2);
                         __builtin_amdgcn_raw_buffer_store_b128(row8(qf[t]), qs, ro, 0, 0);
                         __builtin_amdgcn_raw_buffer_store_b128(row8(kf[t]), ks, ro, 0, 0);
-                        __builtin_amdgcn_raw_buffer_store_b128(row8(vf[t]), vs, ro, 0, 0);
                     }
                 }
                 {
@@ -287,6 +283,33 @@ __global__ __launch_bounds__(FTHREADS, 2) void win_fused_fwd_kernel(FusedArgs a)
                     for (int s = 0; s < 2; ++s)
 #pragma unroll
                         for (int dt = 0; dt < 2; ++dt) vt[s][dt] = pack8(acc[2 * s][dt], acc[2 * s + 1][dt]);
+                }
+                if constexpr (SAVE) {
+                    // V rows for the backward pass from the one orientation computed above (round 3; before: a second, transposed V
+                    // product, 24 MFMAs per head and the registers that made this variant spill): the packed P.V operand vt[s][dt] IS
+                    // V^T as an MFMA A operand, and V^T . E_t with E_t the 0 / 1 matrix that picks token tile t's 16 keys of pair t >> 1
+                    // (in pack8's slot order) lands token 16 t + c's features on lane c -- the layout of q and k.  Exact.
+                    // key slot 8 g + j of a pair = token 4 g + j (j < 4, even tile) or 16 + 4 g + j - 4 (odd tile); lane (c, g) supplies
+                    // column c.  Built here from an opaque copy of the lane index: as loop invariants the two matrices cost 8 registers
+                    // across the whole window loop (spills).
+                    int cz = c;
+                    asm volatile("" : "+v"(cz));
+                    u32x4 et_sel[2];
+#pragma unroll
+                    for (int odd = 0; odd < 2; ++odd)
+#pragma unroll
+                        for (int j2 = 0; j2 < 4; ++j2) {
+                            const int e0 = 2 * (j2 & 1);
+                            const bool mine = (j2 >> 1) == odd;
+                            et_sel[odd][j2] = ((mine && 4 * g + e0 == cz) ? 0x3F80u : 0u) | ((mine && 4 * g + e0 + 1 == cz) ? 0x3F800000u : 0u);
+                        }
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        f32x4 vr[2];
+#pragma unroll
+                        for (int dt = 0; dt < 2; ++dt) vr[dt] = mfma(vt[t >> 1][dt], et_sel[t & 1], f32x4{0.f, 0.f, 0.f, 0.f});
+                        __builtin_amdgcn_raw_buffer_store_b128(row8(pack8(vr[0], vr[1])), vs_save, (unsigned)((16 * t + c) * (HD * 2) + d0 * 2), 0, 0);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 // (SAVE) attention output rows of this head; without SAVE the resource is never used
