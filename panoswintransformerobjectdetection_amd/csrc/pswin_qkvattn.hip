@@ -218,7 +218,7 @@ __global__ __launch_bounds__(QTHREADS, 2) void qkv_attn_fwd_kernel(QkvAttnArgs a
     };
 
     // one (window, head) item of this wave; xs: its rows, xn: the rows of the wave's next item (zero-sized if there is none)
-    auto item = [&]<int PH>(size_t win, rsrc_t xs, rsrc_t xn, const char* bcur, [[maybe_unused]] int fetch_wb, [[maybe_unused]] int qa_k) {
+    auto item = [&]<int PH>(size_t win, rsrc_t xs, rsrc_t xn, const char* bcur, [[maybe_unused]] int qa_k) {
         const size_t row0 = win * TOK;
         QA_STAMP(qa_k);
         f32x4 aq[2][4], ak[2][4], av[4][2];
@@ -325,9 +325,6 @@ __global__ __launch_bounds__(QTHREADS, 2) void qkv_attn_fwd_kernel(QkvAttnArgs a
                 __builtin_amdgcn_raw_buffer_store_b128(row8(pack8(vr[0], vr[1])), vs, ro + 16 * t * (HD * 2), 0, 0);
             }
         }
-#ifdef PSWIN_QA_EARLY_BIAS
-        if (fetch_wb >= 0) fetch_bias(fetch_wb);
-#endif
         __builtin_amdgcn_sched_barrier(0);
         QA_STAMP(qa_k + 2);
         // attention output rows of this head: [49][C] rows, columns 32 hh ..
@@ -399,7 +396,6 @@ __global__ __launch_bounds__(QTHREADS, 2) void qkv_attn_fwd_kernel(QkvAttnArgs a
     for (int wb = wb0; wb < a.nb; wb += wstride, par ^= 1) {
         const char* bcur = bias + par * G::BIAS_BYTES;
         const int wn = wb + wstride;
-        [[maybe_unused]] bool fetched = false;
         for (int rep = wave; rep < a.reps; rep += QWAVES) {
             int nrep = rep + QWAVES, nwb = wb;
             if (nrep >= a.reps) {
@@ -409,20 +405,14 @@ __global__ __launch_bounds__(QTHREADS, 2) void qkv_attn_fwd_kernel(QkvAttnArgs a
             const rsrc_t xn = make_xs(nwb, nrep, nwb < a.nb);
             const size_t win = (size_t)rep * a.nb + wb;
             static_assert(KS % XD == 0, "every item starts at ring slot 0");
-            const bool last = rep + QWAVES >= a.reps;           // this wave's last item of the window
-            item.template operator()<0>(win, xs, xn, bcur, (last && wn < a.nb) ? wn : -1, 4 + 6 * qa_it);
-            fetched = last;
+            item.template operator()<0>(win, xs, xn, bcur, 4 + 6 * qa_it);
             xs = xn;
         }
         // (requesting the next window's quads before the score chain and finishing them here was tried: the sixteen registers they
         // hold across the chain spilled the finish's table indices, whose scratch reloads then waited out the item's stores --
         // 1.8 -> 4.5 us for this phase in the probe)
         if (wn < a.nb) {
-#ifdef PSWIN_QA_EARLY_BIAS
-            if (!fetched) fetch_bias(wn);
-#else
             fetch_bias(wn);
-#endif
             finish_bias(bias + (par ^ 1) * G::BIAS_BYTES);
         }
         QA_STAMP(4 + 6 * qa_it + 4);
