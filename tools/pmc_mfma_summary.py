@@ -21,7 +21,7 @@ NAMES = {"win_fused_fwd_kernel<false>": "pswin_win_attn_fused_fwd (inference)", 
          "qkv_attn_fwd_kernel<384, false>": "pswin_qkv_attn_fused_fwd C=384 (inference)", "qkv_attn_fwd_kernel<384, true>": "pswin_qkv_attn_fused_fwd C=384 (training saves)",
          "attn_fwd_kernel": "pswin_attn_fwd", "attn_bwd_pair_kernel": "pswin_attn_bwd"}
 # in-kernel clock under the kernel's own load, GHz (profiles/r03_fused_window_clock_probe.txt)
-MEASURED_GHZ = {"pswin_win_attn_fused_fwd (inference)": 2.363, "pswin_win_attn_fused_fwd (training saves)": 2.290}
+MEASURED_GHZ = {"pswin_win_attn_fused_fwd (inference)": 2.365, "pswin_win_attn_fused_fwd (training saves)": 2.257}
 out = {"lib_digest": bench._lib_digest(), "counter": "SQ_VALU_MFMA_BUSY_CYCLES (rocprofv3 --pmc, own pass)",
        "measured_clock_source": "profiles/r03_fused_window_clock_probe.txt (median over workgroups of d s_memtime / d s_memrealtime x 100 MHz)", "kernels": {}}
 
