@@ -58,6 +58,20 @@ class _ReduceQueue:
             del d[min(d)]
 
 
+def _graph_task_id():
+    """id of the running backward pass (-1 outside one).  A private torch entry point (present in torch 2.1 .. 2.10): without it
+    nothing is postponed and no gradient slot is handed out -- every reduction launches where it is issued."""
+    f = getattr(torch._C, "_current_graph_task_id", None)
+    return f() if f is not None else -1
+
+
+def deferred_reductions_available():
+    """The two private torch entry points the end-of-pass grouping relies on (the id of the running backward pass and the
+    autograd engine's end-of-pass callback) exist in this torch build."""
+    eng = getattr(torch.autograd.Variable, "_execution_engine", None)
+    return hasattr(torch._C, "_current_graph_task_id") and eng is not None and hasattr(eng, "queue_callback")
+
+
 def set_deferred_reductions(on):
     """on=True: reductions whose result is a PARAMETER gradient (split-K partials of dW, bias-gradient partial rows,
     LayerNorm dgamma / dbeta rows) are queued while autograd runs and issued as one grouped launch when the backward pass
@@ -70,6 +84,9 @@ def set_deferred_reductions(on):
     NOT covered: hooks registered on a parameter's AccumulateGrad NODE (torch DistributedDataParallel's reducer,
     ``grad_fn.register_hook`` consumers) are invisible from Python and would read unfilled gradients -- use dp.GradReducer (which
     this mode is built for) or leave deferral off under DDP.  Returns the previous setting."""
+    if on and not deferred_reductions_available():
+        raise PswinError("set_deferred_reductions(True) needs torch._C._current_graph_task_id and the autograd engine's queue_callback "
+                         f"(private entry points, present in torch 2.1 - 2.10; this is torch {torch.__version__})")
     prev, _ReduceQueue.enabled = _ReduceQueue.enabled, bool(on)
     return prev
 
@@ -126,7 +143,7 @@ def _deferring(owners=()):
     """The job queue of the running backward pass if the reduction that produces the gradients of `owners` (parameters)
     may be postponed to the end of that pass (see set_deferred_reductions; the end-of-pass callback is armed on first
     use), else None = launch now.  Without owners the destination is unknown and nothing is postponed."""
-    task = torch._C._current_graph_task_id() if _ReduceQueue.enabled else -1
+    task = _graph_task_id() if _ReduceQueue.enabled else -1
     owners = [o for o in owners if o is not None]
     if task == -1 or not owners:
         return None
@@ -151,7 +168,7 @@ def flush_if_pending(owners=()):
     autograd would add the two at once -- issue the queue first.  (A module applied to one large and one small input.)"""
     if not _ReduceQueue.enabled:
         return
-    q = _ReduceQueue.tasks.get(torch._C._current_graph_task_id())
+    q = _ReduceQueue.tasks.get(_graph_task_id())
     if q is not None and any(o is not None and o.data_ptr() in q["owners"] for o in owners):
         _launch_queue(q)
 
@@ -164,7 +181,9 @@ def grad_slot(param):
     slot = getattr(param, "_grad_slot", None)
     if slot is None or not param.is_leaf or param.grad is not None or slot.device != param.device or _has_hooks(param):
         return None
-    task = torch._C._current_graph_task_id()
+    task = _graph_task_id()
+    if task == -1:
+        return None
     used = _ReduceQueue.slots.get(task)
     if used is None:
         used = _ReduceQueue.slots[task] = set()
