@@ -373,6 +373,15 @@ int pswin_roi_align_fwd(const pswin_roi_levels* levels, const float* rois, const
 int pswin_roi_align_bwd(const pswin_roi_levels* levels, const float* rois, const int32_t* roi_level, int R, int C, int P, int sampling_ratio,
                         int aligned, int dtype, const void* dout, void* stream);
 
+/* Greedy NMS over `groups` independent lists of boxes sorted by descending score -- the proposal stage of RPNHead (mmcv.ops.nms inside
+ * mmdet/models/dense_heads/rpn_head.py: one list per image and pyramid level): keep[i] = no kept j < i with IoU(i, j) > iou_threshold.
+ * boxes f32 [groups][nmax][4] (x1, y1, x2, y2), counts int32 [groups] (valid boxes per group) or NULL (= nmax everywhere), keep uint8
+ * [groups][nmax] (1 = kept, 0 = suppressed or past the group's count).  nmax <= 2048, a multiple of 64.  Unpinned like RoIAlign (mmcv.ops is not in
+ * the reference tree): tests check it against the sequential rule. */
+int pswin_nms_workspace(int groups, int nmax);                 /* bytes of workspace for pswin_nms_groups (the suppression bit masks); groups <= 2048 */
+int pswin_nms_groups(const float* boxes, const int32_t* counts, int groups, int nmax, float iou_threshold, unsigned char* keep, void* workspace,
+                     void* stream);
+
 int pswin_gemm_nt_supported(long long M, int K, int N);
 int pswin_gemm_nt(const void* x, const void* w, const float* bias, void* y, long long M, int K, int N, int tile_m, void* stream);
 /* The data gradient of the Mlp's fc2 fused with the backward of fc1's bias + nn.GELU (HOT:50-58):

@@ -70,6 +70,8 @@ _PROTOTYPES = {
     "pswin_roi_align_supported": [_i, _i],
     "pswin_roi_align_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
     "pswin_roi_align_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp],
+    "pswin_nms_workspace": [_i, _i],
+    "pswin_nms_groups": [_vp, _vp, _i, _i, ctypes.c_float, _vp, _vp, _vp],
     "pswin_gemm_nt_supported": [ctypes.c_longlong, _i, _i],
     "pswin_gemm_nt": [_vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _i, _vp],
     "pswin_gemm_nt_ring_supported": [ctypes.c_longlong, _i, _i],

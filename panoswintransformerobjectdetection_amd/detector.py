@@ -14,7 +14,7 @@ the reference's configuration numbers (configs/_base_/models/mask_rcnn_swin_fpn.
 PARITY: unpinned.  The reference tree does not contain mmcv.ops (RoIAlign, NMS CUDA sources) nor a fixture for any head,
 so nothing here is checked against reference outputs.  RoIAlign is the published operator with the config's sampling_ratio = 0
 (adaptive grid) as hand-written HIP kernels, forward and backward (csrc/pswin_roi.hip, checked against a plain PyTorch statement
-of the definition in tests/); NMS is the greedy rule evaluated as a fixed-point iteration on the GPU (see nms_keep).  The other
+of the definition in tests/); NMS is the greedy rule: on the GPU one HIP launch per image (nms_keep_groups -> pswin_nms_groups), on the CPU a fixed-point iteration (nms_keep).  The other
 head operators are ordinary PyTorch-ROCm operators (MIOpen / hipBLASLt, bf16 autocast).
 """
 import math
@@ -93,6 +93,15 @@ def nms_keep(boxes, iou_thr, iters=12):
     for _ in range(iters):
         keep = (keep @ over == 0).float()
     return keep.bool()
+
+
+def nms_keep_groups(box_list, iou_thr):
+    """nms_keep for several score-sorted box lists.  On the GPU: the exact greedy rule, all lists in one HIP launch (ops.nms_groups ->
+    pswin_nms_groups; <= 2048 boxes per list); on the CPU (the definition tests): the fixed-point form above, list by list."""
+    if box_list and box_list[0].is_cuda and max(b.shape[0] for b in box_list) <= 2048:
+        from . import ops
+        return ops.nms_groups(box_list, iou_thr)
+    return [nms_keep(b, iou_thr) for b in box_list]
 
 
 # ------------------------------------------------------------------------------------------------------------------------
@@ -256,17 +265,17 @@ class MiniMaskRCNN(nn.Module):
             loss_reg = loss_reg + ((reg_all[b, pos_rank] - d_t).abs().sum(1) * pos_valid.float()).sum() / avg
             # proposals (no gradient): per level top nms_pre, decode, NMS, then the best max_per_img over the levels
             with torch.no_grad():
-                boxes_l, scores_l, at = [], [], 0
+                boxes_l, tops_l, at = [], [], 0
                 for a_l in anchors:
                     n = a_l.shape[0]
                     sc = cls_all[b, at:at + n]
                     k = min(cfg["nms_pre"], n)
                     top, ti = _topk_stable(sc, k)
-                    bx = decode_deltas(a_l[ti], reg_all[b, at:at + n][ti], (1.0, 1.0, 1.0, 1.0), img_hw)
-                    keep = nms_keep(bx, cfg["nms"])
-                    boxes_l.append(bx)
-                    scores_l.append(torch.where(keep, top, top.new_full((), -1e4)))
+                    boxes_l.append(decode_deltas(a_l[ti], reg_all[b, at:at + n][ti], (1.0, 1.0, 1.0, 1.0), img_hw))
+                    tops_l.append(top)
                     at += n
+                keeps = nms_keep_groups(boxes_l, cfg["nms"])                   # the levels of one image: one launch on the GPU
+                scores_l = [torch.where(kp, top, top.new_full((), -1e4)) for kp, top in zip(keeps, tops_l)]
                 bx, sc = torch.cat(boxes_l), torch.cat(scores_l)
                 ti = _topk_stable(sc, min(cfg["max_per_img"], sc.numel()))[1]
                 proposals.append(bx[ti])

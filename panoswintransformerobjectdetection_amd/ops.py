@@ -1563,6 +1563,32 @@ def roi_align_fpn(feats, strides, rois, out_size, sampling_ratio=0, aligned=True
     return _RoiAlignFPN.apply(rois, roi_level, int(out_size), sampling_ratio, aligned, tuple(strides), *feats)
 
 
+_NMS_COUNTS = {}
+
+
+def nms_groups(box_list, iou_thr):
+    """Greedy NMS of several score-sorted box lists in ONE launch (pswin_nms_groups; a workgroup per list): list of bool keep masks.
+    box_list: f32 [n_g, 4] tensors on one HIP device, n_g <= 2048 (the RPN's nms_pre = 2000 per image and pyramid level)."""
+    import ctypes
+    ns = tuple(int(b.shape[0]) for b in box_list)
+    dev = box_list[0].device
+    nmax = -(-max(ns) // 64) * 64                    # the kernels work on whole 64-row chunks
+    if nmax == 0:
+        return [torch.zeros(0, dtype=torch.bool, device=dev) for _ in ns]
+    if nmax > 2048:
+        raise PswinError(f"nms_groups: at most 2048 boxes per list, got {max(ns)}")
+    key = (ns, _dev_key(dev))
+    if key not in _NMS_COUNTS:                      # static per feature-map geometry: no host-to-device copy inside a captured step
+        _NMS_COUNTS[key] = torch.tensor(ns, dtype=torch.int32, device=dev)
+    boxes = torch.zeros(len(ns), nmax, 4, dtype=torch.float32, device=dev)
+    for g, b in enumerate(box_list):
+        boxes[g, :ns[g]] = b.detach().float()
+    keep = torch.empty(len(ns), nmax, dtype=torch.uint8, device=dev)
+    ws = torch.empty(int(_lib.load().pswin_nms_workspace(len(ns), nmax)), dtype=torch.uint8, device=dev)
+    call("pswin_nms_groups", boxes, ptr(boxes), ptr(_NMS_COUNTS[key]), len(ns), nmax, ctypes.c_float(float(iou_thr)), ptr(keep), ptr(ws))
+    return [keep[g, :ns[g]].bool() for g in range(len(ns))]
+
+
 # ------------------------------------------------------------------------------------------------
 # qkv Linear + attention core in one kernel for C = 192 / 384 (pswin_qkv_attn_fused_fwd, round 3)
 # ------------------------------------------------------------------------------------------------

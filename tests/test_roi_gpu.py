@@ -88,3 +88,38 @@ def test_roi_align_rejects_what_it_is_not_built_for(ops):
         ops.roi_align_fpn(feats, STRIDES, _rois(1, 64, 128, 8, 6), 7)
     with pytest.raises(PswinError):
         ops.roi_align_fpn([f.cpu() for f in _pyramid(1, 256, 64, 128, torch.float32, 5)], STRIDES, _rois(1, 64, 128, 8, 6).cpu(), 7)
+
+
+def _greedy(boxes, thr):
+    from panoswintransformerobjectdetection_amd.detector import box_iou
+    iou = box_iou(boxes, boxes).cpu()
+    keep = torch.ones(boxes.shape[0], dtype=torch.bool)
+    for i in range(boxes.shape[0]):
+        if keep[i]:
+            keep &= ~((iou[i] > thr) & (torch.arange(boxes.shape[0]) > i))
+    return keep
+
+
+@pytest.mark.parametrize("thr", [0.7, 0.3])
+def test_nms_groups_is_the_sequential_greedy_rule(ops, thr):
+    """pswin_nms_groups (one workgroup per list, 64-row bit-mask chunks, one wave walking them) against the sequential rule on the same
+    IoU definition: lists of 2000, 1536, 384, 65, 64, 1 and 0 boxes in one launch, dense clusters (long suppression chains), duplicates
+    (IoU exactly 1), degenerate boxes."""
+    g = torch.Generator("cpu").manual_seed(11)
+    lists = []
+    for n in (2000, 1536, 384, 65, 64, 1, 0):
+        c = torch.rand(n, 2, generator=g) * torch.tensor([1024., 512.]) * 0.25        # crowded: many overlaps
+        wh = torch.exp(torch.rand(n, 2, generator=g) * 3.0 + 1.5)
+        b = torch.cat([c - wh / 2, c + wh / 2], 1)
+        if n >= 64:
+            b[5] = b[3]                                                                 # duplicate
+            b[7] = torch.tensor([10., 10., 10., 30.])                                   # zero width
+            b[9, 2:] = b[9, :2] - 1.0                                                   # inverted
+            b[20:60] = b[20:60] * 0 + b[20] + torch.arange(40)[:, None] * 0.5           # a chain of slightly shifted boxes
+        lists.append(b.to(DEV))
+    got = ops.nms_groups(lists, thr)
+    for b, k in zip(lists, got):
+        assert k.dtype == torch.bool and k.shape == (b.shape[0],)
+        assert torch.equal(k.cpu(), _greedy(b.float(), thr)), (b.shape[0], int(k.sum()))
+    with pytest.raises(Exception):
+        ops.nms_groups([torch.zeros(2049, 4, device=DEV)], thr)
