@@ -19,6 +19,8 @@ head operators are ordinary PyTorch-ROCm operators (MIOpen / hipBLASLt, bf16 aut
 """
 import math
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -224,6 +226,13 @@ class MiniMaskRCNN(nn.Module):
                 if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
                     nn.init.normal_(m.weight, std=0.01)
                     nn.init.zeros_(m.bias)
+        # The convolutional heads in channels-last memory format (PSWIN_HEADS_CHANNELS_LAST=0: NCHW) (MIOpen's bf16 kernels are NHWC: in NCHW
+        # every convolution is wrapped in layout transposes, 150 launches / 0.9 ms per step); needs its own find-db records
+        # (tools/miopen_find_heads.sh)
+        self.channels_last = os.environ.get("PSWIN_HEADS_CHANNELS_LAST", "1") != "0"
+        if self.channels_last:
+            for part in (self.neck, self.rpn, self.mask_head):
+                part.to(memory_format=torch.channels_last)
 
     def head_parameters(self):
         bb = {id(p) for p in self.backbone.parameters()}
@@ -346,6 +355,8 @@ class MiniMaskRCNN(nn.Module):
 
     def heads_loss(self, feats, targets, img_hw):
         """Everything behind the backbone: dict of the 5 Mask R-CNN losses (two_stage.py:116-175)."""
+        if self.channels_last:
+            feats = [f.contiguous(memory_format=torch.channels_last) for f in feats]
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=feats[0].is_cuda):
             fpn = self.neck([f for f in feats])
             rpn_outs = self.rpn(fpn)
