@@ -109,6 +109,38 @@ def nms_keep_groups(box_list, iou_thr):
 # ------------------------------------------------------------------------------------------------------------------------
 # neck and heads
 # ------------------------------------------------------------------------------------------------------------------------
+class _AddConvBias(torch.autograd.Function):
+    """y = x + bias[None, :, None, None] whose bias gradient is a fixed-order column sum through the C ABI (ops.colsum on the
+    channels-last rows).  A convolution's own bias gradient is one of the framework's two-pass global reductions
+    (MIOpen ConvolutionBackwardBias / at::sum): 29 launches of ~21 us per step here, and the kind of reduction that returns stale
+    results when a captured hipGraph is replayed (pitfalls) -- the head stand-ins of the step ARE replayed."""
+
+    @staticmethod
+    def forward(ctx, x, bias):
+        ctx.bias_dtype = bias.dtype
+        return x + bias.to(x.dtype).view(1, -1, 1, 1)
+
+    @staticmethod
+    def backward(ctx, dy):
+        C = dy.shape[1]
+        if dy.is_cuda and C % 8 == 0 and dy.dtype in (torch.bfloat16, torch.float32):
+            from . import ops
+            rows = dy.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(-1, C)
+            db = ops.colsum(rows)
+        else:
+            db = dy.float().sum((0, 2, 3))
+        return dy, db.to(ctx.bias_dtype)
+
+
+def conv_bias(m, x):
+    """m(x) for an nn.Conv2d / nn.ConvTranspose2d with the bias added (and its gradient summed) by _AddConvBias"""
+    if isinstance(m, nn.ConvTranspose2d):
+        y = F.conv_transpose2d(x, m.weight, None, m.stride, m.padding, m.output_padding, m.groups, m.dilation)
+    else:
+        y = F.conv2d(x, m.weight, None, m.stride, m.padding, m.dilation, m.groups)
+    return y if m.bias is None else _AddConvBias.apply(y, m.bias)
+
+
 class FPN(nn.Module):
     def __init__(self, in_channels=(96, 192, 384, 768), out_channels=256, num_outs=5):
         super().__init__()
@@ -117,10 +149,10 @@ class FPN(nn.Module):
         self.num_outs = num_outs
 
     def forward(self, feats):
-        lat = [l(f) for l, f in zip(self.lateral, feats)]
+        lat = [conv_bias(l, f) for l, f in zip(self.lateral, feats)]
         for i in range(len(lat) - 1, 0, -1):
             lat[i - 1] = lat[i - 1] + F.interpolate(lat[i], size=lat[i - 1].shape[2:], mode="nearest")
-        outs = [o(x) for o, x in zip(self.output, lat)]
+        outs = [conv_bias(o, x) for o, x in zip(self.output, lat)]
         while len(outs) < self.num_outs:
             outs.append(F.max_pool2d(outs[-1], 1, stride=2))
         return outs
@@ -136,8 +168,8 @@ class RPNHead(nn.Module):
     def forward(self, feats):
         outs = []
         for f in feats:
-            t = F.relu(self.conv(f))
-            outs.append((self.cls(t), self.reg(t)))
+            t = F.relu(conv_bias(self.conv, f))
+            outs.append((conv_bias(self.cls, t), conv_bias(self.reg, t)))
         return outs
 
 
@@ -183,8 +215,8 @@ class MaskHead(nn.Module):
 
     def forward(self, x):
         for c in self.convs:
-            x = F.relu(c(x))
-        return self.logits(F.relu(self.up(x)))
+            x = F.relu(conv_bias(c, x))
+        return conv_bias(self.logits, F.relu(conv_bias(self.up, x)))
 
 
 def roi_align(feats, strides, rois, out_size, finest_scale=56, sampling_ratio=0):
