@@ -9,9 +9,12 @@ A step = forward + backward + gradient average (RCCL, N > 1) + AdamW update of t
 synthetic batch of 8 panoramas per GPU (BASELINE.json configs[1]), bf16 compute with fp32 accumulation /
 master weights.  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 
-`roofline` is measured live: HIP-event pairs around every launch of the hand-written window-attention kernels
-inside the timed region (on the stream they are launched on); algorithmic bytes per window-head are SURVEY.md
-section 8(d)'s: forward 4 x 49 x 32 x 2 B (Q, K, V in, O out), backward 7 x 49 x 32 x 2 B.
+`roofline` is measured live in this run: HIP-event pairs around every launch of the hand-written kernels (on the stream they are
+launched on) in `--kernel-steps` EAGER steps run right after the timed region -- nodes of a replayed hipGraph cannot be bracketed by
+host-recorded events; same kernels, shapes and data, a spin kernel in front of each such step keeps the launches back to back (the
+line's `kernel_timing` field says so too).  The dominant kernel is computed (largest ms/step), its algorithmic bytes / FLOP are
+SURVEY.md section 8(d)'s per-unit figures x the units of the launch (stated next to each call in ops.py; split partial slabs are
+reported as `partial_bytes_per_launch`, never as algorithmic bytes).
 `cpu_baseline` times the CPU oracle (oracle/panoswin_oracle.py, "port") on this box's host cores, rank 0, N = 1.
 """
 import argparse
@@ -69,7 +72,7 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec (MI355X_MICROARCH.md; ~6.3 TB
 MFMA_PEAK_TFLOPS = 2500.0      # dense bf16 MFMA peak (MI355X_MICROARCH.md)
 TIMED = ("pswin_win_attn_fused_fwd", "pswin_qkv_attn_fused_fwd", "pswin_attn_fwd", "pswin_attn_bwd", "pswin_attn_bwd_ex", "pswin_window_gather", "pswin_window_scatter_add",
          "pswin_scatter_add_ln_fwd", "pswin_ln_gather_fwd", "pswin_ln_gather_bwd", "pswin_bias_gelu_fwd", "pswin_bias_gelu_bwd",
-         "pswin_adamw_flat", "pswin_gemm_skinny", "pswin_gemm_nt", "pswin_gemm_nt_gelu_fwd", "pswin_gemm_nt_gelu_bwd", "pswin_gemm_tn", "pswin_gemm_tn_ring", "pswin_gemm_nt_ring", "pswin_roi_align_fwd", "pswin_roi_align_bwd", "pswin_fc1_gelu_fwd", "pswin_fc1_gelu_bwd", "pswin_mlp0_fwd", "pswin_mlp0_bwd", "pswin_stem_conv2_fwd", "pswin_stem_conv3_fwd",
+         "pswin_adamw_flat", "pswin_gemm_skinny", "pswin_gemm_nt", "pswin_gemm_nt_gelu_fwd", "pswin_gemm_nt_gelu_bwd", "pswin_gemm_tn_ring", "pswin_roi_align_fwd", "pswin_roi_align_bwd", "pswin_fc1_gelu_fwd", "pswin_fc1_gelu_bwd", "pswin_mlp0_fwd", "pswin_mlp0_bwd", "pswin_stem_conv2_fwd", "pswin_stem_conv3_fwd",
          "pswin_stem_conv3_bwd_stats", "pswin_stem_conv3_bwd_data", "pswin_stem_conv3_wgrad", "pswin_stem_conv2_wgrad",
          "pswin_stem_conv2_bwd", "lib_gemm_fwd", "lib_gemm_dgrad", "lib_gemm_wgrad")
 # hardware MFMA-pipe utilisation of the window-attention kernels: SQ_VALU_MFMA_BUSY_CYCLES of a separate rocprofv3 --pmc pass
@@ -375,6 +378,9 @@ def main():
                 out.update(bound="hbm", achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(ach / HBM_PEAK_GBS, 4),
                            algorithmic_bytes_per_launch=round(sum(r[1] for r in recs) / len(recs)))
             out["frac_of_mixed_floor"] = round(sum(max(r[1] / (HBM_PEAK_GBS * 1e9), r[2] / (MFMA_PEAK_TFLOPS * 1e12)) for r in recs) / t, 4)
+            pb = sum(r[3] for r in recs)
+            if pb:               # split partial slabs etc.: an implementation artefact, NOT part of the algorithmic bytes `frac` is computed from
+                out["partial_bytes_per_launch"] = round(pb / len(recs))
             return out
 
         # dominant hand-written kernel = the largest ms/step among the timed C-ABI entry points (computed, not assumed)

@@ -293,21 +293,6 @@ int pswin_stem_conv1_wgrad(const float* out5, const float* xx, const void* w1p, 
  * f32 accumulation, bias f32 [N] or NULL.  128 (or 64) x 192 macro tiles, both operands by LDS-DMA into XOR-swizzled
  * double-buffered LDS tiles (csrc/pswin_gemm_nt.hip).  Needs N % 192 == 0, K % 64 == 0, M >= 64 (pswin_gemm_nt_supported).
  * tile_m: 0 = choose, or 64 / 128. */
-/* The same product Y = X . W^T (+ bias) as ONE persistent launch (csrc/pswin_gemm_ntr.hip, round 3): one 8-wave workgroup per CU walks
- * 192 x 192 tiles, the k-steps of consecutive tiles form one stream through a three-stage LDS ring (counted waits, raw barriers), a
- * tile's stores leave under the next tile's steps.  K % 64 == 0, K >= 192, N % 192 == 0; max_wgs: 0 = 256 (one per CU). */
-int pswin_gemm_nt_ring_supported(long long M, int K, int N);
-int pswin_gemm_nt_ring(const void* x, const void* w, const float* bias, void* y, long long M, int K, int N, int max_wgs, void* stream);
-
-/* Weight gradient of a Linear layer: partial[s][n][k] = sum over the rows m of split s of dy[m][n] * x[m][k]  (dW = dY^T X,
- * autograd of HOT:287, 309, 50-58, 575), bf16 operands, f32 partial sums, one [N, K] slab per row split; the caller adds
- * the `splits` slabs (pswin_reduce_jobs).  Both operands are staged row-major in LDS by LDS-DMA and read TRANSPOSED
- * (ds_read_b64_tr_b16): csrc/pswin_gemm_tn.hip.  Needs (K % 128 == 0 and N % 192 == 0) or (K % 192 == 0 and N % 128 == 0);
- * 1 <= splits <= M / 64 (pswin_gemm_tn_splits suggests one); partial: f32 [splits, N, K]. */
-int pswin_gemm_tn_supported(long long M, int N, int K);
-int pswin_gemm_tn_splits(long long M, int N, int K);
-int pswin_gemm_tn(const void* dy, const void* x, float* partial, long long M, int N, int K, int splits, void* stream);
-
 /* The same product with a three-stage LDS ring (counted waits, one raw barrier per 64-row slab, one 8-wave workgroup per CU):
  * csrc/pswin_gemm_tn.hip, "Round 3".  One macro tile of 192 x 192 serves every Linear of the model (N % 192 == 0, K % 192 == 0).
  * partial: [splits, N, K] in `partial_dtype` (PSWIN_F32, or PSWIN_BF16 = each split's tile rounded once, as the library's batched GEMM

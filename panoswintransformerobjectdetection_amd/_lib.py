@@ -56,9 +56,6 @@ _PROTOTYPES = {
     "pswin_stem_bn_fold": [_vp, _vp, ctypes.c_double, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _i, _vp, _vp],
     "pswin_stem_bn2_coefs": [_vp, _vp, ctypes.c_double, _i, _vp, _vp],
     "pswin_stem_conv1_wgrad": [_vp, _vp, _vp, _vp, ctypes.c_double, _i, _vp, _vp, _vp],
-    "pswin_gemm_tn_supported": [ctypes.c_longlong, _i, _i],
-    "pswin_gemm_tn_splits": [ctypes.c_longlong, _i, _i],
-    "pswin_gemm_tn": [_vp, _vp, _vp, ctypes.c_longlong, _i, _i, _i, _vp],
     "pswin_gemm_tn_ring_supported": [ctypes.c_longlong, _i, _i],
     "pswin_gemm_tn_ring_splits": [ctypes.c_longlong, _i, _i, _i],
     "pswin_gemm_tn_ring": [_vp, _vp, _vp, _i, ctypes.c_longlong, _i, _i, _i, _vp],
@@ -74,8 +71,6 @@ _PROTOTYPES = {
     "pswin_nms_groups": [_vp, _vp, _i, _i, ctypes.c_float, _vp, _vp, _vp],
     "pswin_gemm_nt_supported": [ctypes.c_longlong, _i, _i],
     "pswin_gemm_nt": [_vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _i, _vp],
-    "pswin_gemm_nt_ring_supported": [ctypes.c_longlong, _i, _i],
-    "pswin_gemm_nt_ring": [_vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _i, _vp],
     "pswin_gemm_nt_gelu_fwd": [_vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _i, _vp],
     "pswin_gemm_nt_partial_rows": [ctypes.c_longlong, _i],
     "pswin_gemm_nt_gelu_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _i, _vp],
@@ -202,7 +197,9 @@ def stream_of(t):
     return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
 
-# Optional per-launch timing (bench.py): name -> list of (start_event, end_event, algorithmic_bytes, algorithmic_flops).
+# Optional per-launch timing (bench.py): name -> list of (start_event, end_event, algorithmic_bytes, algorithmic_flops, partial_bytes);
+# partial_bytes = bytes of implementation artefacts a launch writes beside its algorithmic output (split partial slabs): reported, never
+# counted as algorithmic traffic.
 # The events are recorded on the stream the kernel is launched on (torch's current stream), around that launch only.
 _TIMED = None
 
@@ -214,13 +211,13 @@ def enable_timing(names):
 
 
 def disable_timing():
-    """Stop collecting; returns {name: [(milliseconds, algorithmic_bytes, algorithmic_flops), ...]} (synchronises)."""
+    """Stop collecting; returns {name: [(milliseconds, algorithmic_bytes, algorithmic_flops, partial_bytes), ...]} (synchronises)."""
     global _TIMED
     rec, _TIMED = _TIMED, None
     if rec is None:
         return {}
     torch.cuda.synchronize()
-    return {n: [(s.elapsed_time(e), b, f) for s, e, b, f in lst] for n, lst in rec.items()}
+    return {n: [(s.elapsed_time(e), b, f, pb) for s, e, b, f, pb in lst] for n, lst in rec.items()}
 
 
 class timed:
@@ -240,11 +237,11 @@ class timed:
     def __exit__(self, *exc):
         if self.rec is not None:
             self.e.record()
-            self.rec.append((self.s, self.e, self.b, self.f))
+            self.rec.append((self.s, self.e, self.b, self.f, 0))
         return False
 
 
-def call(name, ref_tensor, *args, algo_bytes=0, algo_flops=0, timed_as=None):
+def call(name, ref_tensor, *args, algo_bytes=0, algo_flops=0, timed_as=None, partial_bytes=0):
     """Invoke an entry point on the current stream of ref_tensor's device and raise on a non-zero status.
     timed_as: the row of the per-kernel timing table the launch is booked under (default: its own name)."""
     lib = load()
@@ -257,7 +254,7 @@ def call(name, ref_tensor, *args, algo_bytes=0, algo_flops=0, timed_as=None):
             s.record()
             rc = getattr(lib, name)(*args, stream_of(ref_tensor))
             e.record()
-            _TIMED[row].append((s, e, algo_bytes, algo_flops))
+            _TIMED[row].append((s, e, algo_bytes, algo_flops, partial_bytes))
         else:
             rc = getattr(lib, name)(*args, stream_of(ref_tensor))
     check(rc, name)

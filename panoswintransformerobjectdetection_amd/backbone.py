@@ -338,11 +338,7 @@ class _ChannelBias(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        C = dy.shape[1]
-        rows = dy.permute(0, 2, 3, 1).reshape(-1, C)           # a view for channels-last gradients
-        if C % 8:
-            return dy, rows.sum(0, dtype=torch.float32)
-        return dy, ops.colsum(rows)
+        return dy, ops.colsum_channels(dy)                     # any channel count (narrow rows are zero-padded to 8 columns)
 
 
 class PatchEmbed(nn.Module):

@@ -16,7 +16,7 @@ LIB = os.path.join(PKG, "libpswin_hip.so")
 # next to it); the default build ignores both
 EXTRA_FLAGS = os.environ.get("PSWIN_BUILD_FLAGS", "").split()
 OUT = os.environ.get("PSWIN_BUILD_OUT")
-SOURCES = ["pswin_index.hip", "pswin_geom.hip", "pswin_move.hip", "pswin_attn.hip", "pswin_norm.hip", "pswin_bn.hip", "pswin_stem.hip", "pswin_mlp.hip", "pswin_gemm.hip", "pswin_gemm_nt.hip", "pswin_gemm_ntr.hip", "pswin_gemm_tn.hip", "pswin_fused.hip", "pswin_qkvattn.hip", "pswin_optim.hip", "pswin_roi.hip"]
+SOURCES = ["pswin_index.hip", "pswin_geom.hip", "pswin_move.hip", "pswin_attn.hip", "pswin_norm.hip", "pswin_bn.hip", "pswin_stem.hip", "pswin_mlp.hip", "pswin_gemm.hip", "pswin_gemm_nt.hip", "pswin_gemm_tn.hip", "pswin_fused.hip", "pswin_qkvattn.hip", "pswin_optim.hip", "pswin_roi.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]

@@ -95,6 +95,7 @@ def load_checkpoint(model, filename, map_location="cpu", strict=False, logger=No
     if not isinstance(checkpoint, dict):
         raise RuntimeError(f"No state_dict found in checkpoint file {filename}")          # :305-307
     load_state_dict(model, convert_state_dict(checkpoint, model.state_dict()), strict, logger)
-    if hasattr(model, "mark_weights_changed"):
-        model.mark_weights_changed()
+    for m in model.modules():                        # the backbone may sit inside a wrapper (a detector): tell every holder of
+        if hasattr(m, "mark_weights_changed"):       # low-precision weight shadows that the masters changed behind autograd's back
+            m.mark_weights_changed()
     return checkpoint

@@ -227,8 +227,9 @@ class GradReducer:
             return
         for p in module.parameters():
             dist.broadcast(p.data, src=src, group=self.group)
-        if hasattr(module, "mark_weights_changed"):          # p.data writes are invisible to the version counters
-            module.mark_weights_changed()
+        for m in module.modules():                           # p.data writes are invisible to the version counters; the backbone may be
+            if hasattr(m, "mark_weights_changed"):           # nested in a wrapper (MiniMaskRCNN): every shadow holder is told
+                m.mark_weights_changed()
 
 
 # -- backward in two pieces (all-reduce overlapped with the second piece) ------------------------------------------

@@ -19,10 +19,6 @@ FUSED_WINDOW_ATTENTION = os.environ.get("PSWIN_FUSED_ATTN", "1") != "0"
 # the tiled HIP GEMM (pswin_gemm_nt) for the Linear layers of stages 1-3 where it measured faster than the library kernels
 # (profiles/r02_gemm_nt_vs_library.txt); PSWIN_GEMM_NT=0: library GEMMs everywhere (A/B)
 GEMM_NT = os.environ.get("PSWIN_GEMM_NT", "1") != "0"
-# the HIP weight-gradient kernel (pswin_gemm_tn): faster than the library's batched split-K GEMM kernel for kernel on most
-# stage 1-3 shapes (profiles/r02_gemm_tn_split_sweep.txt), but its f32 partial slabs cost the step what the kernel gains
-# (same-box A/B, profiles/r02_ab_gemm.txt): opt-in
-GEMM_TN = os.environ.get("PSWIN_GEMM_TN", "0") != "0"
 # fc2's data gradient + the backward of fc1's bias + GELU in one kernel (pswin_gemm_nt_gelu_bwd); PSWIN_FUSED_GELU_BWD=0: two kernels
 FUSED_GELU_BWD = os.environ.get("PSWIN_FUSED_GELU_BWD", "1") != "0"
 # fc1 with the bias + GELU in its epilogue (pswin_gemm_nt_gelu_fwd) and fc2 as one autograd node; PSWIN_FUSED_MLP=0: GEMM, then a
@@ -676,14 +672,24 @@ def colsum(x2d, zero_cols=None, owners=()):
     return sum_rows(ws, n_ws // N, N, owners=owners)
 
 
+def colsum_channels(dy):
+    """f32 [C]: the sum of an NCHW gradient over batch and pixels (a convolution's bias gradient) as a fixed-order column sum of its
+    channels-last rows, for ANY channel count: rows narrower than / not a multiple of 8 columns (the RPN's 3- and 12-channel heads)
+    are zero-padded to the next multiple of 8 first, so that no framework two-pass reduction -- the kind that returns stale results
+    from the second replay of a captured hipGraph -- is left on the path."""
+    C = dy.shape[1]
+    if dy.dtype not in (torch.bfloat16, torch.float32):
+        dy = dy.float()
+    rows = dy.contiguous(memory_format=torch.channels_last).permute(0, 2, 3, 1).reshape(-1, C)
+    if C % 8:
+        rows = F.pad(rows, (0, 8 - C % 8))
+    return colsum(rows)[:C]
+
+
 def gemm_nt_supported(x2d, n_out):
     """bf16 rows x [n_out, K] weight on the tiled HIP GEMM (pswin_gemm_nt): the Linear layers of stages 1-3"""
     return (x2d.dtype == torch.bfloat16 and x2d.is_cuda and x2d.dim() == 2
             and bool(_lib.load().pswin_gemm_nt_supported(x2d.shape[0], x2d.shape[1], n_out)))
-
-
-# PSWIN_GEMM_NT_ALL=1: every supported shape on the HIP kernel, also the stage-3 ones the isolated measurements gave to the library (A/B)
-GEMM_NT_ALL = os.environ.get("PSWIN_GEMM_NT_ALL", "0") == "1"
 
 
 def gemm_nt_tile(M, K, N):
@@ -693,7 +699,7 @@ def gemm_nt_tile(M, K, N):
     128-row tiles once they give every CU two rounds of work."""
     if not GEMM_NT or not bool(_lib.load().pswin_gemm_nt_supported(M, K, N)):
         return 0
-    if M < 8192 and not (N <= 768 and K <= 1536) and not GEMM_NT_ALL:
+    if M < 8192 and not (N <= 768 and K <= 1536):
         return 0
     return 128 if -(-M // 128) * (N // 192) >= 512 else 64
 
@@ -709,26 +715,6 @@ def transpose_weights(pairs):
         assert dst.shape == (src.shape[1], src.shape[0])
         a.src, a.dst, a.rows, a.cols = src.data_ptr(), dst.data_ptr(), src.shape[0], src.shape[1]
     call("pswin_transpose_jobs", pairs[0][0], ctypes.cast(arr, ctypes.c_void_p), len(pairs))
-
-
-def gemm_tn_splits(M, N, K):
-    """Row splits for the weight-gradient kernel pswin_gemm_tn on dy [M, N], x [M, K], or 0 = leave it to the library."""
-    if not GEMM_TN or M < 4096 or not bool(_lib.load().pswin_gemm_tn_supported(M, N, K)):
-        return 0
-    if 2 * N == K:          # PatchMerging's reduction (4C -> 2C): the library's batched GEMM measured 5-10 % faster
-        return 0
-    return int(_lib.load().pswin_gemm_tn_splits(M, N, K))
-
-
-def gemm_tn(dy, x, splits):
-    """f32 [splits, N, K] partial sums of dy^T x over `splits` row ranges (dy [M, N], x [M, K] bf16)."""
-    dy, x = dy.contiguous(), x.contiguous()
-    M, N = dy.shape
-    K = x.shape[1]
-    part = torch.empty(splits, N, K, dtype=torch.float32, device=x.device)
-    call("pswin_gemm_tn", x, ptr(dy), ptr(x), ptr(part), M, N, K, int(splits),
-         algo_bytes=2 * (M * K + M * N) + 4 * splits * N * K, algo_flops=2 * M * K * N)
-    return part
 
 
 # the three-stage ring kernel for weight gradients (pswin_gemm_tn_ring, round 3); PSWIN_GEMM_TN_RING=0: library batched GEMMs (A/B)
@@ -749,6 +735,8 @@ def gemm_tn_ring_splits(M, N, K):
 
 def gemm_tn_ring(dy, x, splits, out_dtype=torch.float32, bias_sums=False, zero_cols=None):
     """[splits, N, K] partial sums of dy^T x over `splits` row ranges (dy [M, N], x [M, K] bf16) in f32 or bf16.
+    Roofline bookkeeping: algorithmic bytes = dY and X read once + the f32 gradient written once, 2 (MK + MN) + 4 NK; the
+    split partial slabs are an implementation artefact and are reported separately (partial_bytes), never as algorithmic traffic.
     bias_sums=True: also the f32 [splits, N] column sums of dy per row range (the Linear's bias-gradient partials, from the same
     launch; zero_cols=(lo, hi) columns written as zeros) -> (partials, bias partials)."""
     dy, x = dy.contiguous(), x.contiguous()
@@ -757,12 +745,13 @@ def gemm_tn_ring(dy, x, splits, out_dtype=torch.float32, bias_sums=False, zero_c
     part = torch.empty(splits, N, K, dtype=out_dtype, device=x.device)
     if not bias_sums:
         call("pswin_gemm_tn_ring", x, ptr(dy), ptr(x), ptr(part), dtype_code(part), M, N, K, int(splits),
-             algo_bytes=2 * (M * K + M * N) + part.element_size() * splits * N * K, algo_flops=2 * M * K * N)
+             algo_bytes=2 * (M * K + M * N) + 4 * N * K, algo_flops=2 * M * K * N, partial_bytes=part.element_size() * splits * N * K)
         return part
     dbp = torch.empty(splits, N, dtype=torch.float32, device=x.device)
     zlo, zhi = (0, 0) if zero_cols is None else (int(zero_cols[0]), int(zero_cols[1]))
     call("pswin_gemm_tn_ring_bias", x, ptr(dy), ptr(x), ptr(part), dtype_code(part), ptr(dbp), zlo, zhi, M, N, K, int(splits),
-         algo_bytes=2 * (M * K + M * N) + part.element_size() * splits * N * K, algo_flops=2 * M * K * N, timed_as="pswin_gemm_tn_ring")
+         algo_bytes=2 * (M * K + M * N) + 4 * N * K, algo_flops=2 * M * K * N, timed_as="pswin_gemm_tn_ring",
+         partial_bytes=part.element_size() * splits * N * K)
     return part, dbp
 
 
@@ -771,8 +760,6 @@ def gemm_nt(x2d, w, bias=None, tile_m=0):
     x2d, w = x2d.contiguous(), w.contiguous()
     M, K = x2d.shape
     N = w.shape[0]
-    if gemm_nt_ring_ok(M, K, N):                    # (opt-in A/B, see GEMM_NT_RING)
-        return gemm_nt_ring(x2d, w, bias)
     y = torch.empty(M, N, dtype=torch.bfloat16, device=x2d.device)
     b = None if bias is None else bias.detach().float().contiguous()
     call("pswin_gemm_nt", x2d, ptr(x2d), ptr(w), ptr(b), ptr(y), M, K, N, int(tile_m),
@@ -780,38 +767,20 @@ def gemm_nt(x2d, w, bias=None, tile_m=0):
     return y
 
 
-# the persistent ring-pipelined GEMM (pswin_gemm_nt_ring, round 3) instead of the tile-per-workgroup kernel.  Measured and NOT adopted
-# (profiles/r03_gemm_nt_ring_vs_tiled.txt: 1073 vs 950 us per step for the forward pool, 1046 vs 946 for the data gradients; it wins on
-# 5 of 30 shapes by 1-4 us): kept for the record and for A/B (PSWIN_GEMM_NT_RING=1), parity-tested, off by default
-GEMM_NT_RING = os.environ.get("PSWIN_GEMM_NT_RING", "0") != "0"
-GEMM_NT_RING_WGS = int(os.environ.get("PSWIN_GEMM_NT_RING_WGS", "0"))
+def rows_addressable(M, width):
+    """The streaming kernels address their row operands through 32-bit buffer offsets: M rows of `width` bf16 elements must stay below
+    the 0xFFFFFF00 sentinel (the launchers return PSWIN_ERR_ARG otherwise -- the *_supported predicates below check it first, so an
+    oversize batch falls through to the next path instead of raising)."""
+    return M * width * 2 < 0xFFFFFF00
 
 
-def gemm_nt_ring_ok(M, K, N):
-    return GEMM_NT_RING and M >= 4096 and bool(_lib.load().pswin_gemm_nt_ring_supported(M, K, N))
-
-
-def gemm_nt_ring(x2d, w, bias=None):
-    """y = x2d @ w^T (+ bias) on the persistent ring kernel: x2d [M, K] bf16, w [N, K] bf16, bias f32 [N] or None -> [M, N] bf16."""
-    x2d, w = x2d.contiguous(), w.contiguous()
-    M, K = x2d.shape
-    N = w.shape[0]
-    y = torch.empty(M, N, dtype=torch.bfloat16, device=x2d.device)
-    b = None if bias is None else bias.detach().float().contiguous()
-    call("pswin_gemm_nt_ring", x2d, ptr(x2d), ptr(w), ptr(b), ptr(y), M, K, N, GEMM_NT_RING_WGS,
-         algo_bytes=2 * (M * K + M * N + N * K), algo_flops=2 * M * K * N)
-    return y
-
-
-# PSWIN_SKINNY_FC2_DGRAD=1: stage-0 fc2 data gradient ([M, 96] x [96, 384]) on the streaming kernel instead of the library (83 us per launch inside
-# the step).  Measured same box: the streaming kernel takes 91 us there, 717.6 vs 724.8 panoramas/s -- off by default (profiles/r03_ab_small_switches.txt)
-SKINNY_FC2_DGRAD = os.environ.get("PSWIN_SKINNY_FC2_DGRAD", "0") == "1"
+def skinny_gemm_shape_ok(M, K, N):
+    return M >= 4096 and rows_addressable(M, max(K, N)) and bool(_lib.load().pswin_gemm_skinny_supported(K, N))
 
 
 def skinny_gemm_supported(x2d, n_out):
     """bf16 rows x a small weight: the shapes pswin_gemm_skinny is instantiated for (stage-0 projections, stage-1 proj)"""
-    return (x2d.dtype == torch.bfloat16 and x2d.is_cuda and x2d.shape[0] >= 4096
-            and bool(_lib.load().pswin_gemm_skinny_supported(x2d.shape[1], n_out)))
+    return x2d.dtype == torch.bfloat16 and x2d.is_cuda and skinny_gemm_shape_ok(x2d.shape[0], x2d.shape[1], n_out)
 
 
 def skinny_gemm(x2d, w, bias=None, transpose_w=False):
@@ -886,15 +855,15 @@ def linear_backward(x, wb, dy, weight, bias, zero_bias_cols, need_dx, wbt=None):
         # data gradient with the streaming kernel (weight transposed while it is staged) where that beats the library:
         # the three stage-0 shapes with 96 output columns and the stage-0 fc2 (96 -> 384 columns)
         tile = gemm_nt_tile(M, N, K) if (wbt is not None and dy.dtype == torch.bfloat16) else 0
-        if ((K == 96 and N in (96, 288, 384)) or (N == 96 and K == 384 and SKINNY_FC2_DGRAD)) and skinny_gemm_supported(dy, K):
+        if K == 96 and N in (96, 288, 384) and skinny_gemm_supported(dy, K):
             dx = skinny_gemm(dy, wb, None, transpose_w=True)
         elif tile:
             dx = gemm_nt(dy, wbt, None, tile)
         else:
             with _lib.timed("lib_gemm_dgrad", 2 * (M * K + M * N + N * K), 2 * M * K * N):
                 dx = dy @ wb
-    sp = gemm_tn_splits(M, N, K) if dy.dtype == torch.bfloat16 else 0
-    rs = gemm_tn_ring_splits(M, N, K) if (dy.dtype == torch.bfloat16 and not sp) else 0
+    sp = 0
+    rs = gemm_tn_ring_splits(M, N, K) if dy.dtype == torch.bfloat16 else 0
     db_part = None
     if rs:                                                   # the ring-pipelined HIP weight-gradient kernel; the bias gradient rides along
         pdt = torch.bfloat16 if (GEMM_TN_RING_BF16 and rs > 1) else torch.float32
@@ -903,8 +872,6 @@ def linear_backward(x, wb, dy, weight, bias, zero_bias_cols, need_dx, wbt=None):
         else:
             part = gemm_tn_ring(dy, x, rs, pdt)
         ch, sp = rs, rs
-    elif sp:                                                 # (opt-in) the two-stage HIP kernel of round 2, f32 partial slabs
-        part, ch = gemm_tn(dy, x, sp), sp
     else:
         ch = _pick_split(M, -(-N // 64) * -(-K // 64))
         with _lib.timed("lib_gemm_wgrad", 2 * (M * K + M * N) + 4 * N * K, 2 * M * K * N):
@@ -1046,10 +1013,17 @@ MLP0_FUSED = os.environ.get("PSWIN_MLP0_FUSED", "1") != "0"
 MLP0_FUSED_FWD = os.environ.get("PSWIN_MLP0_FUSED_FWD", "1") != "0"
 
 
+def mlp0_fused_shape_ok(M, C, hidden):
+    """pswin_mlp0_fwd / _bwd take [M, C] rows and an [M, hidden] activation: both must be 32-bit addressable (M < ~5.6 M rows at
+    hidden = 384: batch 170 at 512 x 1024, batch 42 at 1024 x 2048); larger batches fall through to the unfused path."""
+    lib = _lib.load()
+    return (M >= 4096 and rows_addressable(M, max(C, hidden)) and bool(lib.pswin_mlp0_bwd_supported(C, hidden))
+            and fc1_gelu_shape_ok(M, C, hidden) and skinny_gemm_shape_ok(M, hidden, C))
+
+
 def mlp0_fused_supported(x2d, hidden):
-    return (MLP0_FUSED and x2d.dtype == torch.bfloat16 and x2d.is_cuda and x2d.dim() == 2 and x2d.shape[0] >= 4096
-            and bool(_lib.load().pswin_mlp0_bwd_supported(x2d.shape[1], hidden)) and fc1_gelu_supported(x2d, hidden)
-            and bool(_lib.load().pswin_gemm_skinny_supported(hidden, x2d.shape[1])))
+    return (MLP0_FUSED and x2d.dtype == torch.bfloat16 and x2d.is_cuda and x2d.dim() == 2
+            and mlp0_fused_shape_ok(x2d.shape[0], x2d.shape[1], hidden))
 
 
 def mlp0_fused(x2d, fc1, fc2):
@@ -1058,9 +1032,12 @@ def mlp0_fused(x2d, fc1, fc2):
     return _Mlp0.apply(x2d, fc1.weight, fc1.bias, fc2.weight, l1[0] if l1 is not None else None, l2[0] if l2 is not None else None)
 
 
+def fc1_gelu_shape_ok(M, K, N):
+    return M >= 4096 and rows_addressable(M, max(K, N)) and bool(_lib.load().pswin_fc1_gelu_supported(K, N))
+
+
 def fc1_gelu_supported(x2d, n_out):
-    return (x2d.dtype == torch.bfloat16 and x2d.is_cuda and x2d.shape[0] >= 4096
-            and bool(_lib.load().pswin_fc1_gelu_supported(x2d.shape[1], n_out)))
+    return x2d.dtype == torch.bfloat16 and x2d.is_cuda and fc1_gelu_shape_ok(x2d.shape[0], x2d.shape[1], n_out)
 
 
 def fc1_gelu(x2d, weight, bias, w_lp=None):
@@ -1484,8 +1461,13 @@ class _WindowAttentionFused(torch.autograd.Function):
         return dx, dwq, dbq, dwp, dalpha, dbeta, None, None, None, None, None, None, None, None
 
 
+def fused_windows_addressable(n_windows, C):
+    """the bound the fused attention launchers enforce on the packed q, k, v save: n_windows * 49 * 3C * 2 bytes < 0x7fffffff00"""
+    return n_windows * WTOK * 3 * C * 2 < 0x7fffffff00
+
+
 def window_attention_fused_supported(x2d, heads):
-    return (x2d.is_cuda and x2d.dim() == 2 and x2d.dtype == torch.bfloat16
+    return (x2d.is_cuda and x2d.dim() == 2 and x2d.dtype == torch.bfloat16 and fused_windows_addressable(x2d.shape[0] // WTOK, x2d.shape[1])
             and bool(_lib.load().pswin_win_attn_fused_supported(x2d.shape[1], heads, BF16)))
 
 
@@ -1643,6 +1625,7 @@ class _WindowAttentionQkvFused(torch.autograd.Function):
 
 def window_attention_qkv_fused_supported(x2d, heads):
     return (FUSED_QKV_ATTENTION and x2d.is_cuda and x2d.dim() == 2 and x2d.dtype == torch.bfloat16
+            and fused_windows_addressable(x2d.shape[0] // WTOK, x2d.shape[1])
             and bool(_lib.load().pswin_qkv_attn_fused_supported(x2d.shape[1], heads, BF16)))
 
 

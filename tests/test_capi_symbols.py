@@ -57,8 +57,8 @@ def test_argument_errors_of_the_round_2_entry_points_without_a_gpu():
     assert lib.pswin_gemm_nt_gelu_bwd(p16, p16, p16, p16, p16, None, 16384, 384, 1536, 128, None) == ERR  # partial sums buffer
     assert lib.pswin_gemm_nt_partial_rows(16384, 128) == 128 and lib.pswin_gemm_nt_partial_rows(16385, 64) == 257
     assert lib.pswin_gemm_nt_partial_rows(16384, 100) == ERR
-    assert lib.pswin_gemm_tn_supported(16384, 1152, 384) == 1 and lib.pswin_gemm_tn_supported(16384, 576, 192) == 0
-    assert lib.pswin_gemm_tn(p16, p16, p16, 16384, 1152, 384, 0, None) == ERR                             # splits >= 1
+    assert lib.pswin_gemm_tn_ring_supported(16384, 1152, 384) == 1 and lib.pswin_gemm_tn_ring_supported(16384, 576, 200) == 0
+    assert lib.pswin_gemm_tn_ring(p16, p16, p16, 1, 16384, 1152, 384, 0, None) == ERR                     # splits >= 1
     # fused window kernel: C = 96 / 3 heads / bf16 only
     assert lib.pswin_win_attn_fused_supported(96, 3, 1) == 1 and lib.pswin_win_attn_fused_supported(192, 6, 1) == 0
     assert lib.pswin_win_attn_fused_supported(96, 3, 0) == 0
@@ -128,3 +128,20 @@ def test_checkpoint_loader_semantics(tmp_path):
     dst2 = SimplePanoSwinTransformer(**cfg)
     dst2.init_weights(str(path))
     assert torch.equal(dst2.state_dict()["patch_embed.proj.0.weight"], sd["patch_embed.proj.0.weight"])
+
+
+def test_supported_predicates_send_oversize_batches_to_the_unfused_path():
+    """pswin_mlp0_fwd / _bwd, pswin_gemm_skinny and pswin_fc1_gelu_* reject row operands past the 32-bit buffer range with
+    PSWIN_ERR_ARG; the Python predicates must say "unsupported" for those sizes first (so the caller falls through to the next path)
+    and keep saying "supported" for the benched ones.  Shape logic only -- no kernel runs."""
+    from panoswintransformerobjectdetection_amd import ops
+    M_bench = 8 * 128 * 256                                         # PanoSwin-T stage 0 at batch 8
+    assert ops.mlp0_fused_shape_ok(M_bench, 96, 384) and ops.fc1_gelu_shape_ok(M_bench, 96, 384)
+    assert ops.skinny_gemm_shape_ok(M_bench, 96, 288) and ops.skinny_gemm_shape_ok(M_bench, 384, 96)
+    M_big = 171 * 128 * 256                                         # batch 171 at 512 x 1024: M * 384 * 2 >= 0xFFFFFF00
+    assert M_big * 384 * 2 >= 0xFFFFFF00 > (M_big - 128 * 256) * 384 * 2
+    assert not ops.mlp0_fused_shape_ok(M_big, 96, 384) and not ops.fc1_gelu_shape_ok(M_big, 96, 384)
+    assert not ops.skinny_gemm_shape_ok(M_big, 384, 96) and ops.skinny_gemm_shape_ok(M_big, 96, 96)
+    assert ops.mlp0_fused_shape_ok(M_big - 128 * 256, 96, 384)
+    assert not ops.mlp0_fused_shape_ok(2048, 96, 384)               # tiny inputs stay on the generic path as before
+    assert ops.fused_windows_addressable(8 * 703, 96) and not ops.fused_windows_addressable(1 << 26, 384)

@@ -112,3 +112,19 @@ def test_paramwise_groups_follow_the_mmcv_rule():
     pw = dict(custom_keys={"norm": dict(decay_mult=0.), "layers.0.blocks.0.norm1": dict(lr_mult=2.0)})
     got = {n: (a, b) for n, a, b in paramwise_groups(named, pw)}
     assert got["layers.0.blocks.0.norm1.weight"] == (2.0, 1.0) and got["layers.0.blocks.1.norm1.weight"] == (1.0, 0.0)
+
+
+def test_loading_through_a_wrapper_marks_the_nested_backbone_weights_changed(tmp_path):
+    """load_checkpoint on a detector-like wrapper writes the nested backbone's weights; its low-precision shadows are stale
+    unless the BACKBONE's epoch is bumped (mark_weights_changed on every submodule that has it)."""
+    class Wrapper(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.backbone = SimplePanoSwinTransformer(**TINY, pano_mode=True)
+
+    w = Wrapper()
+    path = tmp_path / "wrapped.pth"
+    torch.save({"state_dict": w.state_dict()}, path)
+    before = w.backbone.__dict__.get("_lowp_epoch", 0)
+    load_checkpoint(w, str(path), strict=False)
+    assert w.backbone.__dict__.get("_lowp_epoch", 0) == before + 1

@@ -197,3 +197,45 @@ def _configs2_body(side):
             assert all(bool(torch.isfinite(p.grad).all()) for p in heads)
     finally:
         _ops.set_deferred_reductions(prev)
+
+
+def test_conv_bias_gradients_of_every_width_stay_fresh_across_graph_replays():
+    """the heads' convolution bias gradients all go through the C ABI's fixed-order column sums -- also the RPN's 3- and
+    12-channel convolutions, whose rows are zero-padded to 8 columns -- because the framework's two-pass reductions return stale results
+    from the second replay of a captured hipGraph.  The captured step is replayed four times on different data; every bias gradient of
+    every replay must equal the sum of THAT replay's own output gradient."""
+    from panoswintransformerobjectdetection_amd.detector import conv_bias
+    from panoswintransformerobjectdetection_amd.graph import GraphedCallable
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        torch.manual_seed(0)
+        convs = [torch.nn.Conv2d(16, c, k, padding=k // 2).to(DEV) for c, k in ((3, 1), (12, 1), (256, 3), (80, 1))]
+        deconv = torch.nn.ConvTranspose2d(16, 20, 2, stride=2).to(DEV)
+        x = torch.randn(2, 16, 40, 72, device=DEV)
+        wts = [torch.zeros(2, c.out_channels, 40, 72, device=DEV) for c in convs] + [torch.zeros(2, 20, 80, 144, device=DEV)]
+        mods = convs + [deconv]
+
+        def step():
+            for m in mods:
+                m.bias.grad = None
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                total = sum((conv_bias(m, x).float() * w).sum() for m, w in zip(mods, wts))
+            total.backward()
+            return total.detach()
+
+        for w in wts:
+            w.normal_()
+        g = GraphedCallable(step, warmup=2, stream=side, parameters=mods)
+        for replay in range(4):
+            for w in wts:
+                w.normal_()                                         # new output gradients for this replay
+            g()
+            side.synchronize()
+            for m, w in zip(mods, wts):
+                want = w.to(torch.bfloat16).double().sum((0, 2, 3))    # dy of the bf16 convolution output is w rounded to bf16
+                got = m.bias.grad.double()
+                scale = w.abs().sum((0, 2, 3)).double()
+                assert torch.all((got - want).abs() <= 1e-3 * scale + 1e-6), (replay, m.out_channels, (got - want).abs().max())
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()

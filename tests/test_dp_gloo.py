@@ -259,3 +259,41 @@ def test_logged_loss_scalars_are_averaged_with_one_collective():
     from panoswintransformerobjectdetection_amd.dp import reduce_loss_scalars
     one = reduce_loss_scalars({"b": torch.tensor(2.0), "a": torch.tensor(1.0)})             # no process group: identity
     assert list(one) == ["a", "b"] and float(one["a"]) == 1.0 and float(one["b"]) == 2.0
+
+
+def _nested_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(1)
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    for p in (os.path.dirname(here), here):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    from _util import TINY
+    from panoswintransformerobjectdetection_amd import SimplePanoSwinTransformer
+    from panoswintransformerobjectdetection_amd.dp import GradReducer, init_distributed
+    init_distributed(backend="gloo")
+
+    class Wrapper(torch.nn.Module):                  # the backbone nested in a detector-like holder (MiniMaskRCNN's shape)
+        def __init__(self):
+            super().__init__()
+            torch.manual_seed(rank)
+            self.backbone = SimplePanoSwinTransformer(**TINY, pano_mode=True)
+            self.head = torch.nn.Linear(4, 4)
+
+    w = Wrapper()
+    before = w.backbone.__dict__.get("_lowp_epoch", 0)
+    red = GradReducer(w)
+    red.broadcast_parameters(w)
+    same = float(sum(p.double().sum() for p in w.parameters()))
+    q.put((rank, before, w.backbone.__dict__.get("_lowp_epoch", 0), same))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_broadcast_through_a_wrapper_marks_the_nested_backbone_weights_changed():
+    """broadcast_parameters writes p.data of a backbone nested in a wrapper; the backbone's bf16 weight shadows are refreshed
+    on the next forward pass only if ITS epoch is bumped (mark_weights_changed on every submodule that has it, not on the wrapper)."""
+    res = sorted(_run_ranks(_nested_worker, ()))
+    assert [r[1] for r in res] == [0, 0] and [r[2] for r in res] == [1, 1]
+    assert res[0][3] == res[1][3]                    # and the broadcast itself made the ranks equal

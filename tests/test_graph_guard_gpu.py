@@ -1,0 +1,64 @@
+"""GPU side of the one-stream guard: the order that crashed hipStreamEndCapture in round 3 -- an eager step on the
+default stream whose loss is still referenced, then a capture on a side stream -- now raises PswinError before anything is captured;
+once the earlier graph is released (or everything runs on one stream) the capture goes through and replays correctly.  The test never
+reaches capture_end in the bad state: it checks that the guard raises, not that the crash reproduces."""
+import pytest
+import torch
+
+from panoswintransformerobjectdetection_amd._lib import PswinError
+from panoswintransformerobjectdetection_amd.graph import GraphedCallable, GraphedSequence
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _setup():
+    torch.manual_seed(0)
+    m = torch.nn.Sequential(torch.nn.Linear(64, 64), torch.nn.GELU(), torch.nn.Linear(64, 8)).to(DEV)
+    x = torch.randn(32, 64, device=DEV)
+
+    def step():
+        for p in m.parameters():
+            p.grad = None
+        loss = m(x).square().mean()
+        loss.backward()
+        return loss.detach()
+    return m, x, step
+
+
+def test_capture_after_an_eager_step_on_another_stream_is_refused_with_a_python_exception():
+    m, x, step = _setup()
+    loss = m(x).square().mean()                 # eager pass on the default stream: AccumulateGrad nodes are created there ...
+    loss.backward()
+    torch.cuda.synchronize()
+    with pytest.raises(PswinError) as e:         # ... and `loss` keeps them alive
+        GraphedCallable(step, warmup=2, parameters=[m])
+    assert "ONE stream" in str(e.value) and "AccumulateGrad" in str(e.value)
+    with pytest.raises(PswinError):
+        GraphedSequence([step], warmup=1, parameters=[m])
+    assert not torch.cuda.is_current_stream_capturing()
+    del loss                                     # the earlier graph is gone: its nodes die, the guard creates them on the capture stream
+    g = GraphedCallable(step, warmup=2, parameters=[m])
+    ref = [p.grad.clone() for p in m.parameters()]
+    for _ in range(3):
+        out = g()
+    torch.cuda.synchronize()
+    assert torch.isfinite(out)
+    for p, r in zip(m.parameters(), ref):
+        assert torch.equal(p.grad, r)
+
+
+def test_everything_on_one_side_stream_is_accepted_without_listing_parameters():
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        m, x, step = _setup()
+        loss = m(x).square().mean()             # still referenced, but created on the capture stream: fine
+        loss.backward()
+        g = GraphedCallable(step, warmup=2, stream=side)     # parameters=None: every HIP parameter alive in the process
+        want = step().clone()
+        got = g()
+        side.synchronize()
+        assert torch.allclose(got, want)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()

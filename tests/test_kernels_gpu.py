@@ -826,56 +826,6 @@ def test_linear_on_the_tiled_gemm_matches_the_library_path(ops):
 
 
 @pytest.mark.parametrize("M,N,K,splits", [(19600, 1152, 384, 0), (16384, 384, 1536, 0), (4096, 768, 3072, 7), (5880, 2304, 768, 0),
-                                          (333, 192, 128, 3), (64, 128, 192, 1), (74480, 768, 192, 0), (1000, 384, 384, 15)])
-def test_gemm_tn_against_torch(ops, M, N, K, splits):
-    """pswin_gemm_tn (LDS-DMA slabs, both operands read transposed from LDS, f32 partial slabs per row split) against an
-    fp32 matmul of the same bf16 operands; ragged M (the last slab of the last split reads past M: zeros), both macro-tile
-    orientations."""
-    from panoswintransformerobjectdetection_amd import _lib
-    lib = _lib.load()
-    torch.manual_seed(M + N + K)
-    dy = torch.randn(M, N, device=DEV).to(torch.bfloat16)
-    x = torch.randn(M, K, device=DEV).to(torch.bfloat16)
-    assert lib.pswin_gemm_tn_supported(M, N, K) == 1
-    sp = splits or lib.pswin_gemm_tn_splits(M, N, K)
-    assert 1 <= sp <= M // 64
-    part = ops.gemm_tn(dy, x, sp)
-    assert part.shape == (sp, N, K) and part.dtype == torch.float32
-    got = part.sum(0)
-    ref = dy.float().t() @ x.float()
-    assert torch.allclose(got, ref, rtol=2e-3, atol=2e-3 * float(ref.abs().max())), (got - ref).abs().max()
-    assert lib.pswin_gemm_tn_supported(M, 576, 192) == 0 and lib.pswin_gemm_tn_supported(M, N + 64, K) == 0
-
-
-@pytest.mark.parametrize("M,K,N,wgs", [(19600, 384, 1152, 0), (16384, 1536, 384, 0), (4096, 768, 3072, 0), (5880, 768, 768, 0), (74480, 192, 576, 0),
-                                       (333, 192, 192, 0), (192, 256, 384, 0), (1000, 384, 384, 8), (5000, 192, 192, 16), (4099, 576, 960, 24)])
-@pytest.mark.parametrize("with_bias", [False, True])
-def test_gemm_nt_ring_against_torch(ops, M, K, N, wgs, with_bias):
-    """pswin_gemm_nt_ring (one persistent 8-wave workgroup per CU, the k-steps of consecutive 192 x 192 tiles as one stream through a
-    three-stage LDS ring, counted waits across tile boundaries and epilogue stores) against an fp32 matmul of the same bf16 operands:
-    ragged M, 3 .. 24 k-steps per tile, 1 .. 60 tiles per workgroup (small grids force long tile sequences), with and without bias."""
-    from panoswintransformerobjectdetection_amd import _lib
-    lib = _lib.load()
-    torch.manual_seed(M + N + K)
-    x = torch.randn(M, K, device=DEV).to(torch.bfloat16)
-    w = (torch.randn(N, K, device=DEV) / math.sqrt(K)).to(torch.bfloat16)
-    b = torch.randn(N, device=DEV) if with_bias else None
-    assert lib.pswin_gemm_nt_ring_supported(M, K, N) == 1
-    prev = ops.GEMM_NT_RING_WGS
-    ops.GEMM_NT_RING_WGS = wgs
-    try:
-        y = ops.gemm_nt_ring(x, w, b)
-    finally:
-        ops.GEMM_NT_RING_WGS = prev
-    ref = x.float() @ w.float().t() + (b if with_bias else 0)
-    assert y.shape == (M, N) and y.dtype == torch.bfloat16
-    assert torch.allclose(y.float(), ref, rtol=1e-2, atol=1e-2 * float(ref.abs().max())), (y.float() - ref).abs().max()
-    if M * N <= 19600 * 1152 and not with_bias:                 # same arithmetic as the tile-per-workgroup kernel: same bits
-        assert torch.equal(y, ops.gemm_nt(x, w, None, 64 if M < 8192 else 128)) or float((y.float() - ops.gemm_nt(x, w, None, 64).float()).abs().max()) <= 2 ** -6 * float(ref.abs().max())
-    assert lib.pswin_gemm_nt_ring_supported(M, K, N + 64) == 0 and lib.pswin_gemm_nt_ring_supported(M, 128, N) == 0
-
-
-@pytest.mark.parametrize("M,N,K,splits", [(19600, 1152, 384, 0), (16384, 384, 1536, 0), (4096, 768, 3072, 7), (5880, 2304, 768, 0),
                                           (74480, 576, 192, 0), (74480, 192, 192, 0), (333, 192, 192, 3), (64, 192, 192, 1), (130, 384, 192, 2),
                                           (1000, 384, 384, 15), (4033, 192, 576, 63),
                                           # stage 0: the whole gradient in one tile (K = 96: qkv, proj, fc1; fc2 with K = 384, N = 96)

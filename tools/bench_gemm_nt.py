@@ -54,9 +54,7 @@ def main():
         hf = [t(lambda: ops.gemm_nt(x, w, None, tm)) if ops.gemm_nt_supported(x, N) else float("nan") for tm in (64, 128)]
         hd = [t(lambda: ops.gemm_nt(dy, wt, None, tm)) if ops.gemm_nt_supported(dy, K) else float("nan") for tm in (64, 128)]
         fl = max(2 * (M * K + M * N + N * K) / 6.3e12, 2.0 * M * K * N / 2.5e15) * 1e6
-        lib = ops._lib.load()
-        rf = t(lambda: ops.gemm_nt_ring(x, w)) if lib.pswin_gemm_nt_ring_supported(M, K, N) else float("nan")
-        rd = t(lambda: ops.gemm_nt_ring(dy, wt)) if lib.pswin_gemm_nt_ring_supported(M, N, K) else float("nan")
+        rf = rd = float("nan")            # (the persistent ring variant of round 3 was removed in round 4: profiles/r03_gemm_nt_ring_vs_tiled.txt)
         print(f"{name:8s} {M:6d} {K:5d} {N:5d} | {lf:8.1f} {hf[0]:6.1f} {hf[1]:6.1f} {rf:6.1f} | {ld:10.1f} {hd[0]:6.1f} {hd[1]:6.1f} {rd:6.1f} | {fl:6.1f}   | x{cnt}", flush=True)
         tot["ring_fwd"] += (rf if rf == rf else lf) * cnt
         tot["ring_dgrad"] += (rd if rd == rd else ld) * cnt

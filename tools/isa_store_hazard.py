@@ -17,15 +17,23 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "panoswintransformerobjectdetection_amd", "csrc")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-ffp-contract=off", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC, "--cuda-device-only", "-S"]
+sys.path.insert(0, ROOT)
+from panoswintransformerobjectdetection_amd.build import FLAGS as BUILD_FLAGS, SOURCES  # noqa: E402  (the library's own flags and source list)
+
+FLAGS = [f for f in BUILD_FLAGS if f != "-fPIC"] + ["--cuda-device-only", "-S"]
+ANY_STORE = re.compile(r"^\s*buffer_store_dwordx[34]\s")
+# kernel sources known to issue 128-bit buffer stores: a scan that sees none of them in one of these did not scan that file
+EXPECT_STORES = ("pswin_stem.hip", "pswin_qkvattn.hip", "pswin_fused.hip", "pswin_attn.hip")
 STORE = re.compile(r"^\s*buffer_store_dwordx[34]\s+v\[(\d+):(\d+)\],\s*(?:v\d+|off),\s*s\[\d+:\d+\],\s*(s\d+|\d+|0x[0-9a-f]+)")
 VDST = re.compile(r"^\s*(v_\w+)\s+v(?:\[(\d+):(\d+)\]|(\d+))")
 
 
-def scan(path):
+def scan(path, stats=None):
     bad = 0
     lines = open(path).read().split("\n")
     kern = "?"
+    if stats is not None:
+        stats[os.path.basename(path)[:-2]] = sum(1 for ln in lines if ANY_STORE.match(ln))
     for i, ln in enumerate(lines):
         m = re.match(r"^(_Z\w+):", ln)
         if m:
@@ -55,18 +63,34 @@ def scan(path):
 
 
 def main():
-    bad = 0
+    """0: every source of the library compiled and scanned, no occurrence; 1: occurrences; 2: the scan itself is not trustworthy (a
+    source did not compile, an ISA file is missing, or a file expected to contain 128-bit buffer stores shows none)."""
+    bad, broken, stats = 0, 0, {}
     with tempfile.TemporaryDirectory() as d:
         procs = []
-        for src in sorted(glob.glob(os.path.join(CSRC, "*.hip"))):
+        srcs = [os.path.join(CSRC, f) for f in SOURCES]
+        extra = sorted(set(glob.glob(os.path.join(CSRC, "*.hip"))) - set(srcs))
+        for src in srcs + extra:
             out = os.path.join(d, os.path.basename(src) + ".s")
-            procs.append((out, subprocess.Popen(["/opt/rocm/bin/hipcc"] + FLAGS + ["-o", out, src], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)))
-        for out, p in procs:
-            p.wait()
-            if os.path.exists(out):
-                bad += scan(out)
+            procs.append((src, out, subprocess.Popen(["/opt/rocm/bin/hipcc"] + FLAGS + ["-o", out, src], stdout=subprocess.PIPE,
+                                                     stderr=subprocess.STDOUT, text=True)))
+        for src, out, p in procs:
+            log, _ = p.communicate()
+            if p.returncode != 0 or not os.path.exists(out):
+                print(f"{os.path.basename(src)}: hipcc exit {p.returncode}, ISA {'missing' if not os.path.exists(out) else 'present'}\n{log}")
+                broken += 1
+                continue
+            bad += scan(out, stats)
+    for name in EXPECT_STORES:
+        if name in stats and stats[name] == 0:
+            print(f"{name}: no buffer_store_dwordx3/x4 seen -- the pattern no longer matches this compiler's output")
+            broken += 1
+        elif name not in stats:
+            print(f"{name}: not scanned")
+            broken += 1
+    print("scanned:", {k: v for k, v in sorted(stats.items())})
     print("occurrences:", bad)
-    return 1 if bad else 0
+    return 2 if broken else (1 if bad else 0)
 
 
 if __name__ == "__main__":
