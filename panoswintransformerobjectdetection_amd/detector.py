@@ -42,6 +42,44 @@ def box_iou(a, b):
     return inter / (area_a[:, None] + area_b[None] - inter).clamp(min=1e-6)
 
 
+def box_iof(a, b):
+    """intersection over the area of the FIRST box (mmdet bbox_overlaps(mode='iof')): [N, 4] x [M, 4] -> [N, M]"""
+    area_a = (a[:, 2] - a[:, 0]).clamp(min=0) * (a[:, 3] - a[:, 1]).clamp(min=0)
+    lt = torch.max(a[:, None, :2], b[None, :, :2])
+    rb = torch.min(a[:, None, 2:], b[None, :, 2:])
+    wh = (rb - lt).clamp(min=0)
+    return wh[..., 0] * wh[..., 1] / area_a[:, None].clamp(min=1e-6)
+
+
+def max_iou_assign(bboxes, gt_bboxes, pos_iou_thr, neg_iou_thr, min_pos_iou=0.0, match_low_quality=True, gt_bboxes_ignore=None,
+                   ignore_iof_thr=-1.0, ignore_wrt_candidates=True):
+    """MaxIoUAssigner.assign (mmdet/core/bbox/assigners/max_iou_assigner.py:85-212; gt_max_assign_all=True): long [N] with
+    -1 = ignore, 0 = negative, i + 1 = positive matched to gt i.  Pinned by the reference's own vectors
+    (tests/test_utils/test_assigner.py:14-151 -> tests/golden/detector_reference_vectors.json).  No host synchronisation and static
+    shapes for non-empty inputs (the step is captured in a hipGraph): the reference's sequential low-quality loop, in which a later
+    gt overwrites an earlier one, is the maximum over the matching gt indices."""
+    N, G = bboxes.shape[0], gt_bboxes.shape[0]
+    inds = torch.full((N,), -1, dtype=torch.long, device=bboxes.device)
+    if N == 0 or G == 0:
+        return inds.zero_() if G == 0 else inds                                                   # :147-153
+    overlaps = box_iou(gt_bboxes, bboxes)                                                         # [G, N]  (:105)
+    if ignore_iof_thr > 0 and gt_bboxes_ignore is not None and gt_bboxes_ignore.numel() > 0:    # :107-117
+        if ignore_wrt_candidates:
+            ign = box_iof(bboxes, gt_bboxes_ignore).max(1)[0]
+        else:
+            ign = box_iof(gt_bboxes_ignore, bboxes).max(0)[0]
+        overlaps = torch.where((ign > ignore_iof_thr)[None], overlaps.new_full((), -1.0), overlaps)
+    best, arg = overlaps.max(0)
+    inds = torch.where((best >= 0) & (best < neg_iou_thr), torch.zeros_like(inds), inds)          # :170-172
+    inds = torch.where(best >= pos_iou_thr, arg + 1, inds)                                        # :179-180
+    if match_low_quality:                                                                         # :182-197
+        gbest = overlaps.max(1)[0]
+        hit = (overlaps == gbest[:, None]) & (gbest[:, None] >= min_pos_iou)
+        last = (hit.long() * torch.arange(1, G + 1, device=bboxes.device)[:, None]).max(0)[0]
+        inds = torch.where(last > 0, last, inds)
+    return inds
+
+
 _CONSTS = {}
 
 
@@ -175,18 +213,23 @@ _ANCHORS = {}
 
 
 def make_anchors(shapes, strides, device, scale=8.0, ratios=(0.5, 1.0, 2.0)):
-    """AnchorGenerator(scales=[8], ratios=[0.5, 1, 2]): per level [H * W * 3, 4], location-major (the conv output order).
-    Cached per geometry: constants of the step (and building them copies host data, which a hipGraph capture refuses)."""
+    """AnchorGenerator(scales=[8], ratios=[0.5, 1, 2]).grid_anchors (mmdet/core/anchor/anchor_generator.py; center_offset 0,
+    scale_major): per level [H * W * 3, 4], location-major with x fastest (the conv output order).  A stride may be an (x, y) pair; the
+    base size is then min(stride), as in the reference.  Layout pinned by tests/test_utils/test_anchor.py:22-40 of the reference
+    (tests/golden/detector_reference_vectors.json).  Cached per geometry: constants of the step (and building them copies host data,
+    which a hipGraph capture refuses)."""
+    strides = [tuple(s) if isinstance(s, (tuple, list)) else (s, s) for s in strides]
     key = (tuple(tuple(int(v) for v in sh) for sh in shapes), tuple(strides), str(device), scale, tuple(ratios))
     if key in _ANCHORS:
         return _ANCHORS[key]
     out = []
-    for (H, W), s in zip(shapes, strides):
+    for (H, W), (stx, sty) in zip(shapes, strides):
+        s = min(stx, sty)
         r = torch.tensor(ratios, device=device)
         hr, wr = torch.sqrt(r), 1.0 / torch.sqrt(r)
         ws, hs = s * scale * wr, s * scale * hr
         base = torch.stack([-0.5 * ws, -0.5 * hs, 0.5 * ws, 0.5 * hs], 1)                         # centred on the cell corner
-        sy, sx = torch.meshgrid(torch.arange(H, device=device) * s, torch.arange(W, device=device) * s, indexing="ij")
+        sy, sx = torch.meshgrid(torch.arange(H, device=device) * sty, torch.arange(W, device=device) * stx, indexing="ij")
         shift = torch.stack([sx, sy, sx, sy], -1).reshape(-1, 1, 4).float()
         out.append((shift + base[None]).reshape(-1, 4))
     _ANCHORS[key] = out
@@ -280,14 +323,11 @@ class MiniMaskRCNN(nn.Module):
         proposals = []
         for b in range(B):
             gt = targets[b]["boxes"]
-            iou = box_iou(flat_a, gt)                                                             # [A, G]
-            best, arg = iou.max(1)
-            label = torch.full_like(best, -1)
-            label[best < cfg["neg"]] = 0
-            label[best >= cfg["pos"]] = 1
-            gbest = iou.max(0)[0]                                                                 # low-quality matches
-            lq = ((iou == gbest[None]) & (gbest[None] >= cfg["min_pos"])).any(1)
-            label[lq] = 1
+            # MaxIoUAssigner(pos 0.7, neg 0.3, min_pos 0.3, match_low_quality) -- configs/_base_/models/mask_rcnn_swin_fpn.py:79-85
+            gt_inds = max_iou_assign(flat_a, gt, cfg["pos"], cfg["neg"], cfg["min_pos"], True)
+            label = gt_inds.clamp(max=1).to(flat_a.dtype)                                         # 1 positive, 0 negative, -1 neither
+            arg = (gt_inds - 1).clamp(min=0)
+            best = label
             # random sampling with static shapes: rank by a random key, positives first
             key = self.rand_like(best)
             pos_rank = torch.argsort(torch.where(label == 1, key, key + 2))[:n_pos_max]
@@ -329,9 +369,10 @@ class MiniMaskRCNN(nn.Module):
             for b, props in enumerate(proposals):
                 gt, gl = targets[b]["boxes"], targets[b]["labels"]
                 cand = torch.cat([gt, props], 0)                                                  # add_gt_as_proposals
-                iou = box_iou(cand, gt)
-                best, arg = iou.max(1)
-                is_pos = best >= cfg["pos"]
+                # MaxIoUAssigner(pos 0.5, neg 0.5, min_pos 0.5, match_low_quality=True) -- mask_rcnn_swin_fpn.py:101-107
+                gt_inds = max_iou_assign(cand, gt, cfg["pos"], cfg["pos"], cfg["pos"], True)
+                is_pos, arg = gt_inds > 0, (gt_inds - 1).clamp(min=0)
+                best = is_pos.float()
                 key = self.rand_like(best)
                 pos_rank = torch.argsort(torch.where(is_pos, key, key + 2))[:n_pos_max]
                 pos_valid = is_pos[pos_rank]

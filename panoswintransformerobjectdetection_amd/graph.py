@@ -80,6 +80,9 @@ class AccumulateStreamGuard:
         if not bad:
             return
         label = (names or {}).get(id(self.params[bad[0]]), f"a parameter of shape {tuple(self.params[bad[0]].shape)}")
+        # the exception's traceback keeps this object alive for as long as the caller holds it: let go of the nodes now, so that they can
+        # die with the graph that owns them and a retry (after `del loss`) finds fresh ones
+        self.nodes = []
         raise PswinError(
             f"hipGraph capture refused: the AccumulateGrad nodes of {len(bad)} of {len(self.seen)} parameters (first: {label}) run on "
             f"{self.seen[bad[0]]}, not on the capture stream {stream}.  They were created by an earlier forward pass on that stream and "
