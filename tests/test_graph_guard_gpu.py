@@ -39,13 +39,17 @@ def test_capture_after_an_eager_step_on_another_stream_is_refused_with_a_python_
     assert not torch.cuda.is_current_stream_capturing()
     del loss                                     # the earlier graph is gone: its nodes die, the guard creates them on the capture stream
     g = GraphedCallable(step, warmup=2, parameters=[m])
-    ref = [p.grad.clone() for p in m.parameters()]
     for _ in range(3):
         out = g()
     torch.cuda.synchronize()
     assert torch.isfinite(out)
-    for p, r in zip(m.parameters(), ref):
-        assert torch.equal(p.grad, r)
+    got = [p.grad.clone() for p in m.parameters()]
+    with torch.cuda.stream(g.stream):             # the same step eagerly, on the capture stream
+        want = step().clone()
+    torch.cuda.synchronize()
+    assert torch.allclose(out, want)
+    for p, r in zip(m.parameters(), got):
+        assert torch.allclose(p.grad, r, rtol=1e-5, atol=1e-7)
 
 
 def test_everything_on_one_side_stream_is_accepted_without_listing_parameters():
