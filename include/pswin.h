@@ -308,6 +308,23 @@ int pswin_gemm_tn_ring(const void* dy, const void* x, void* partial, int partial
 int pswin_gemm_tn_ring_bias(const void* dy, const void* x, void* partial, int partial_dtype, float* dbias_partial, int zero_lo, int zero_hi,
                             long long M, int N, int K, int splits, void* stream);
 
+/* Several weight gradients in ONE launch per tile geometry (round 4).  A weight gradient is not needed before the backward pass ends,
+ * so the host can queue them (ops.py: deferred weight gradients) and issue them together: with ~50 products in flight at once no
+ * product needs a 256-way row split to fill the chip, so every workgroup contracts a few thousand rows and the partial-slab traffic
+ * (256 x 192 x 192 x 2 B = 18.9 MB per product when each is launched alone) falls with the split count; per-launch ramps disappear.
+ * Jobs are independent; each is the argument list of pswin_gemm_tn_ring_bias.  `jobs` is a HOST array (copied into the kernel
+ * arguments, <= 48 jobs per launch and geometry; list the longest row ranges first).  splits == 1 with partial_dtype == PSWIN_F32 writes
+ * the finished [N, K] gradient (no reduction needed). */
+typedef struct pswin_tn_job {
+    const void* dy;       /* bf16 [M, N] */
+    const void* x;        /* bf16 [M, K] */
+    void* partial;        /* [splits, N, K] in partial_dtype */
+    float* dbias_partial; /* f32 [splits, N] or NULL */
+    long long M;
+    int N, K, splits, partial_dtype, zero_lo, zero_hi;
+} pswin_tn_job;
+int pswin_gemm_tn_ring_jobs(const pswin_tn_job* jobs, int n_jobs, void* stream);
+
 typedef struct pswin_transpose_job {
     const void* src; /* bf16 [rows][cols] */
     void* dst;       /* bf16 [cols][rows] */

@@ -60,6 +60,7 @@ _PROTOTYPES = {
     "pswin_gemm_tn_ring_splits": [ctypes.c_longlong, _i, _i, _i],
     "pswin_gemm_tn_ring": [_vp, _vp, _vp, _i, ctypes.c_longlong, _i, _i, _i, _vp],
     "pswin_gemm_tn_ring_bias": [_vp, _vp, _vp, _i, _vp, _i, _i, ctypes.c_longlong, _i, _i, _i, _vp],
+    "pswin_gemm_tn_ring_jobs": [_vp, _i, _vp],
     "pswin_transpose_jobs": [_vp, _i, _vp],
     "pswin_adamw_flat": [_vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _vp, _vp],
     "pswin_adamw_flat_groups": [_vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _vp, _i, _vp, _vp, ctypes.c_double, ctypes.c_double,
@@ -126,6 +127,13 @@ class ReduceJob(ctypes.Structure):
     """pswin_reduce_job of include/pswin.h"""
     _fields_ = [("src", ctypes.c_void_p), ("dst", ctypes.c_void_p), ("dtype", ctypes.c_int), ("rows", ctypes.c_int),
                 ("cols", ctypes.c_int), ("ld", ctypes.c_int)]
+
+
+class TnJob(ctypes.Structure):
+    """pswin_tn_job of include/pswin.h"""
+    _fields_ = [("dy", ctypes.c_void_p), ("x", ctypes.c_void_p), ("partial", ctypes.c_void_p), ("dbias_partial", ctypes.c_void_p),
+                ("M", ctypes.c_longlong), ("N", ctypes.c_int), ("K", ctypes.c_int), ("splits", ctypes.c_int), ("partial_dtype", ctypes.c_int),
+                ("zero_lo", ctypes.c_int), ("zero_hi", ctypes.c_int)]
 
 
 class TransposeJob(ctypes.Structure):

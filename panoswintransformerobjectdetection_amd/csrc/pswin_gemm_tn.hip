@@ -83,11 +83,46 @@ __device__ inline void wait_frags(Frag (&a)[6], Frag (&b)[3]) {
                  : "memory");
 }
 
-template <int WK, int WN, int STAGES, bool OUT_BF16>
-__global__ __launch_bounds__(RING_THREADS, 2) void gemm_tn_ring_kernel(const unsigned short* __restrict__ DY, const unsigned short* __restrict__ X,
-                                                                        void* __restrict__ P, int M, int N, int K, int tiles_k, int tiles_n,
-                                                                        int rows_per_split, float* __restrict__ DB, int zero_lo, int zero_hi) {
+// Round 4: the kernel takes a TABLE of independent products (job = one Linear's dW; the table travels in the kernel arguments, as
+// pswin_reduce_jobs' does).  Why: a weight gradient is not needed before the backward pass ends, so the host can hold the ~50 of them
+// back and issue them together (ops.py: deferred weight gradients).  One launch of many products needs no 256-way row split per
+// product to fill the chip -- every workgroup then contracts >= 2,048 rows instead of ~1,000 (at batch 2: instead of ~250), which
+// halves (batch 2: removes most of) the partial-slab traffic and the per-launch ramps: 51 launches of 15-30 us become three.
+struct TnJob {
+    const unsigned short* dy;
+    const unsigned short* x;
+    void* part;
+    float* db;
+    int M, N, K, tiles_k, tiles_n, rows_per_split, zero_lo, zero_hi;
+    int first_wg, n_wg, out_bf16, pad_;
+};
+constexpr int TN_JOBS_MAX = 48;                        // 48 x 80 B: the kernel-argument segment holds 4 KB
+struct TnBatch {
+    TnJob job[TN_JOBS_MAX];
+    int n;
+};
+
+template <int WK, int WN, int STAGES>
+__global__ __launch_bounds__(RING_THREADS, 2) void gemm_tn_ring_kernel(const TnBatch batch) {
     using G = RingGeom<WK, WN, STAGES>;
+    // this workgroup's job: first_wg ascending (multiples of 8, so that a job's workgroups keep the round-robin XCD pattern of a launch
+    // of its own); workgroups past a job's count are padding and leave at once
+    int jlo = 0, jhi = batch.n - 1;
+    while (jlo < jhi) {
+        const int mid = (jlo + jhi + 1) >> 1;
+        if (batch.job[mid].first_wg <= (int)blockIdx.x) jlo = mid;
+        else jhi = mid - 1;
+    }
+    const TnJob& job = batch.job[jlo];
+    const int jbid = (int)blockIdx.x - job.first_wg, nwg = job.n_wg;
+    if (jbid >= nwg) return;
+    const unsigned short* __restrict__ DY = job.dy;
+    const unsigned short* __restrict__ X = job.x;
+    void* __restrict__ P = job.part;
+    float* __restrict__ DB = job.db;
+    const int M = job.M, N = job.N, K = job.K, tiles_k = job.tiles_k, tiles_n = job.tiles_n, rows_per_split = job.rows_per_split;
+    const int zero_lo = job.zero_lo, zero_hi = job.zero_hi;
+    const bool out_bf16 = job.out_bf16 != 0;
     constexpr int IA = 6, JB = 3;                      // 16-wide tiles per wave along k (96 columns) / n (48 columns)
     constexpr int RING_STAGE_BYTES = G::STAGE_BYTES, LOADS = G::LOADS;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -96,10 +131,10 @@ __global__ __launch_bounds__(RING_THREADS, 2) void gemm_tn_ring_kernel(const uns
     const int c = lane & 15, g = lane >> 4;
     const int wk = wave / WN, wn = wave - wk * WN;
 
-    const int ntiles = tiles_k * tiles_n, nwg = gridDim.x;
+    const int ntiles = tiles_k * tiles_n;
     int t;
     {
-        const int bid = blockIdx.x, q = nwg / 8, r = nwg % 8, xcd = bid % 8, loc = bid / 8;
+        const int bid = jbid, q = nwg / 8, r = nwg % 8, xcd = bid % 8, loc = bid / 8;
         t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
     }
     const int split = t / ntiles, tile = t - split * ntiles;
@@ -271,7 +306,7 @@ __global__ __launch_bounds__(RING_THREADS, 2) void gemm_tn_ring_kernel(const uns
             const int k = k0 + wk * 96 + 16 * i + 4 * g;
             if (k >= K) continue;
             const size_t o = (size_t)split * N * K + (size_t)n * K + k;
-            if constexpr (OUT_BF16) {
+            if (out_bf16) {
                 *reinterpret_cast<u32x2*>(reinterpret_cast<unsigned short*>(P) + o) = u32x2{pack2_bf16(acc[i][j][0], acc[i][j][1]), pack2_bf16(acc[i][j][2], acc[i][j][3])};
             } else {
                 *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(P) + o) = acc[i][j];
@@ -280,26 +315,73 @@ __global__ __launch_bounds__(RING_THREADS, 2) void gemm_tn_ring_kernel(const uns
     }
 }
 
-template <int WK, int WN, int STAGES, bool OUT_BF16>
-int launch_tn_ring(const void* dy, const void* x, void* partial, int M, int N, int K, int splits, hipStream_t st, float* db, int zero_lo, int zero_hi) {
-    using G = RingGeom<WK, WN, STAGES>;
-    constexpr size_t lds = (size_t)STAGES * G::STAGE_BYTES;
-    static std::atomic<unsigned long long> configured{0};
-    if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&gemm_tn_ring_kernel<WK, WN, STAGES, OUT_BF16>), lds, configured)) return rc;
-    const int tiles_k = (K + 96 * WK - 1) / (96 * WK), tiles_n = (N + 48 * WN - 1) / (48 * WN);
-    const int rows_per_split = ((M + splits - 1) / splits + MSTEP - 1) / MSTEP * MSTEP;
-    hipLaunchKernelGGL((gemm_tn_ring_kernel<WK, WN, STAGES, OUT_BF16>), dim3(tiles_k * tiles_n * splits), dim3(RING_THREADS), lds, st,
-                       reinterpret_cast<const unsigned short*>(dy), reinterpret_cast<const unsigned short*>(x), partial, M, N, K, tiles_k, tiles_n,
-                       rows_per_split, db, zero_lo, zero_hi);
-    PSWIN_LAUNCH_RET();
-}
-
 // geometry for a shape: 0 = <2, 4> (192 x 192 tiles), 1 = <1, 8> (K = 96, N <= 384), 2 = <4, 2> (K = 384, N = 96), -1 = none
 inline int ring_geom(int N, int K) {
     if (N >= 192 && K >= 192 && N % 192 == 0 && K % 192 == 0) return 0;
     if (K == 96 && N >= 48 && N <= 384 && N % 16 == 0) return 1;
     if (K == 384 && N == 96) return 2;
     return -1;
+}
+
+template <int WK, int WN, int STAGES>
+int launch_tn_batch(const TnBatch& b, int wgs, hipStream_t st) {
+    using G = RingGeom<WK, WN, STAGES>;
+    constexpr size_t lds = (size_t)STAGES * G::STAGE_BYTES;
+    static std::atomic<unsigned long long> configured{0};
+    if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&gemm_tn_ring_kernel<WK, WN, STAGES>), lds, configured)) return rc;
+    hipLaunchKernelGGL((gemm_tn_ring_kernel<WK, WN, STAGES>), dim3(wgs), dim3(RING_THREADS), lds, st, b);
+    PSWIN_LAUNCH_RET();
+}
+
+inline bool tn_job_ok(const pswin_tn_job& q) {
+    return q.dy && q.x && q.partial && q.M >= 64 && (q.M + 64) * (long long)(q.K > q.N ? q.K : q.N) * 2 < 0xFFFFFF00ll && ring_geom(q.N, q.K) >= 0 &&
+           q.splits >= 1 && q.splits <= q.M / 64 && valid_dtype(q.partial_dtype) && aligned16(q.dy) && aligned16(q.x) && aligned16(q.partial) &&
+           q.zero_lo >= 0 && q.zero_hi >= q.zero_lo && q.zero_hi <= q.N;
+}
+
+// every job of `geom` in the caller's order, <= TN_JOBS_MAX per launch; the caller lists the longest row ranges first (the hardware
+// deals workgroups in order: longest-first keeps the tail of the launch short)
+int launch_tn_jobs(const pswin_tn_job* jobs, int n_jobs, int geom, hipStream_t st) {
+    TnBatch b;
+    b.n = 0;
+    long long wgs = 0;
+    auto flush = [&]() -> int {
+        if (b.n == 0) return PSWIN_OK;
+        int rc;
+        if (geom == 0) rc = launch_tn_batch<2, 4, 3>(b, (int)wgs, st);
+        else if (geom == 1) rc = launch_tn_batch<1, 8, 2>(b, (int)wgs, st);
+        else rc = launch_tn_batch<4, 2, 2>(b, (int)wgs, st);
+        b.n = 0;
+        wgs = 0;
+        return rc;
+    };
+    for (int i = 0; i < n_jobs; ++i) {
+        const pswin_tn_job& q = jobs[i];
+        if (ring_geom(q.N, q.K) != geom) continue;
+        const int tk = geom == 0 ? 192 : (geom == 1 ? 96 : 384), tn = geom == 0 ? 192 : (geom == 1 ? 384 : 96);
+        TnJob& j = b.job[b.n];
+        j.dy = reinterpret_cast<const unsigned short*>(q.dy);
+        j.x = reinterpret_cast<const unsigned short*>(q.x);
+        j.part = q.partial;
+        j.db = q.dbias_partial;
+        j.M = (int)q.M;
+        j.N = q.N;
+        j.K = q.K;
+        j.tiles_k = (q.K + tk - 1) / tk;
+        j.tiles_n = (q.N + tn - 1) / tn;
+        j.rows_per_split = (int)(((q.M + q.splits - 1) / q.splits + MSTEP - 1) / MSTEP * MSTEP);
+        j.zero_lo = q.zero_lo;
+        j.zero_hi = q.zero_hi;
+        j.first_wg = (int)wgs;
+        j.n_wg = j.tiles_k * j.tiles_n * q.splits;
+        j.out_bf16 = q.partial_dtype == PSWIN_BF16;
+        j.pad_ = 0;
+        wgs += (j.n_wg + 7) / 8 * 8;
+        if (++b.n == TN_JOBS_MAX || wgs > (1ll << 24)) {
+            if (const int rc = flush()) return rc;
+        }
+    }
+    return flush();
 }
 
 }  // namespace
@@ -322,27 +404,29 @@ int pswin_gemm_tn_ring_splits(long long M, int N, int K, int target_wgs) {
     return s < 1 ? 1 : s;
 }
 
+int pswin_gemm_tn_ring_jobs(const pswin_tn_job* jobs, int n_jobs, void* stream) {
+    PSWIN_CHECK_ARG(jobs && n_jobs > 0);
+    for (int i = 0; i < n_jobs; ++i) PSWIN_CHECK_ARG(tn_job_ok(jobs[i]));
+    for (int geom = 0; geom < 3; ++geom)
+        if (const int rc = launch_tn_jobs(jobs, n_jobs, geom, (hipStream_t)stream)) return rc;
+    return PSWIN_OK;
+}
+
 int pswin_gemm_tn_ring_bias(const void* dy, const void* x, void* partial, int partial_dtype, float* dbias_partial, int zero_lo, int zero_hi, long long M,
                             int N, int K, int splits, void* stream) {
-    PSWIN_CHECK_ARG(dy && x && partial && pswin_gemm_tn_ring_supported(M, N, K) && splits >= 1 && splits <= M / 64 && valid_dtype(partial_dtype));
-    PSWIN_CHECK_ARG(aligned16(dy) && aligned16(x) && aligned16(partial));
-    PSWIN_CHECK_ARG(zero_lo >= 0 && zero_hi >= zero_lo && zero_hi <= N);
-    const bool bf = partial_dtype == PSWIN_BF16;
-    const hipStream_t st = (hipStream_t)stream;
-    float* db = dbias_partial;
-    const int m = (int)M;
-    switch (ring_geom(N, K)) {
-        case 0:
-            return bf ? launch_tn_ring<2, 4, 3, true>(dy, x, partial, m, N, K, splits, st, db, zero_lo, zero_hi)
-                      : launch_tn_ring<2, 4, 3, false>(dy, x, partial, m, N, K, splits, st, db, zero_lo, zero_hi);
-        case 1:
-            return bf ? launch_tn_ring<1, 8, 2, true>(dy, x, partial, m, N, K, splits, st, db, zero_lo, zero_hi)
-                      : launch_tn_ring<1, 8, 2, false>(dy, x, partial, m, N, K, splits, st, db, zero_lo, zero_hi);
-        case 2:
-            return bf ? launch_tn_ring<4, 2, 2, true>(dy, x, partial, m, N, K, splits, st, db, zero_lo, zero_hi)
-                      : launch_tn_ring<4, 2, 2, false>(dy, x, partial, m, N, K, splits, st, db, zero_lo, zero_hi);
-        default: return PSWIN_ERR_UNSUPPORTED;
-    }
+    pswin_tn_job q;
+    q.dy = dy;
+    q.x = x;
+    q.partial = partial;
+    q.dbias_partial = dbias_partial;
+    q.M = M;
+    q.N = N;
+    q.K = K;
+    q.splits = splits;
+    q.partial_dtype = partial_dtype;
+    q.zero_lo = zero_lo;
+    q.zero_hi = zero_hi;
+    return pswin_gemm_tn_ring_jobs(&q, 1, stream);
 }
 
 int pswin_gemm_tn_ring(const void* dy, const void* x, void* partial, int partial_dtype, long long M, int N, int K, int splits, void* stream) {

@@ -43,6 +43,7 @@ class _ReduceQueue:
     # autograd graph task id -> jobs queued by that backward pass.  Keyed by task because passes nest (the backward of a
     # torch.utils.checkpoint segment is a pass of its own inside the outer one); each pass flushes its own jobs.
     #   "jobs": (src tensor, byte offset, dtype code, rows, cols, ld, dst tensor)
+    #   "wgrad_jobs": weight gradients held back for the grouped launch (dy, x, partial, bias partial or None, M, N, K, splits, zero_lo, zero_hi)
     #   "table_jobs": attention table gradients waiting for their binning launch (after the reductions)
     #   "owners": data_ptr of every parameter that already has a postponed gradient in this pass
     tasks = {}
@@ -113,9 +114,32 @@ def _launch_table_grads(jobs, stages=3):
         call("pswin_attn_table_grads_batch", lst[0][0], ctypes.cast(arr, ctypes.c_void_p), len(lst), stages)
 
 
+def _launch_wgrads(jobs):
+    """The queued weight gradients as ONE pswin_gemm_tn_ring_jobs call per device (one kernel launch per tile geometry): longest row
+    ranges first, so that the tail of the launch is made of the short ones."""
+    import ctypes
+    by_dev = {}
+    for j in jobs:
+        by_dev.setdefault(j[0].device, []).append(j)
+    for lst in by_dev.values():
+        lst = sorted(lst, key=lambda j: -(j[4] // j[7]))
+        arr = (_lib.TnJob * len(lst))()
+        nbytes = flops = pbytes = 0
+        for a, (dy, x, part, dbp, M, N, K, splits, zlo, zhi) in zip(arr, lst):
+            a.dy, a.x, a.partial, a.dbias_partial = dy.data_ptr(), x.data_ptr(), part.data_ptr(), (None if dbp is None else dbp.data_ptr())
+            a.M, a.N, a.K, a.splits, a.partial_dtype, a.zero_lo, a.zero_hi = M, N, K, splits, dtype_code(part), zlo, zhi
+            nbytes += 2 * (M * K + M * N) + 4 * N * K
+            flops += 2 * M * K * N
+            pbytes += part.element_size() * splits * N * K if splits > 1 else 0
+        call("pswin_gemm_tn_ring_jobs", lst[0][0], ctypes.cast(arr, ctypes.c_void_p), len(lst), algo_bytes=nbytes, algo_flops=flops,
+             timed_as="pswin_gemm_tn_ring", partial_bytes=pbytes)
+
+
 def _launch_queue(q):
-    jobs, tjobs = q["jobs"], q["table_jobs"]
-    q["jobs"], q["table_jobs"] = [], []
+    jobs, tjobs, wjobs = q["jobs"], q["table_jobs"], q["wgrad_jobs"]
+    q["jobs"], q["table_jobs"], q["wgrad_jobs"] = [], [], []
+    if wjobs:
+        _launch_wgrads(wjobs)                           # the reductions below sum their partial slabs
     if jobs:
         _launch_reductions(jobs)
     if tjobs:
@@ -147,7 +171,7 @@ def _deferring(owners=()):
         return None                  # a non-leaf "owner" feeds further autograd nodes right away
     q = _ReduceQueue.tasks.get(task)
     if q is None:
-        q = _ReduceQueue.tasks[task] = {"jobs": [], "table_jobs": [], "owners": set()}
+        q = _ReduceQueue.tasks[task] = {"jobs": [], "table_jobs": [], "wgrad_jobs": [], "owners": set()}
         _ReduceQueue.trim(_ReduceQueue.tasks)
         torch.autograd.Variable._execution_engine.queue_callback(lambda: flush_reductions(task))
     keys = [o.data_ptr() for o in owners]
@@ -726,10 +750,60 @@ GEMM_TN_RING_WGS = int(os.environ.get("PSWIN_GEMM_TN_RING_WGS", "0"))
 GEMM_TN_RING_BIAS = os.environ.get("PSWIN_GEMM_TN_RING_BIAS", "1") != "0"
 
 
+# Weight gradients held back to the end of the backward pass and issued as one launch per tile geometry (pswin_gemm_tn_ring_jobs) when
+# the parameter-gradient reductions are deferred too (set_deferred_reductions): a workgroup then contracts GROUPED_WGRAD_ROWS rows
+# instead of M / (256 / tiles).  PSWIN_GROUPED_WGRAD=0: one launch per weight gradient, where autograd produces it (A/B)
+GROUPED_WGRAD = os.environ.get("PSWIN_GROUPED_WGRAD", "1") != "0"
+GROUPED_WGRAD_ROWS = int(os.environ.get("PSWIN_GROUPED_WGRAD_ROWS", "2048"))
+
+
+def grouped_wgrad_splits(M):
+    """row splits of one weight gradient inside the grouped launch: about GROUPED_WGRAD_ROWS rows per workgroup"""
+    return max(1, min(M // 64, (M + GROUPED_WGRAD_ROWS // 2) // GROUPED_WGRAD_ROWS))
+
+
+def queue_weight_gradient(dy, x, weight, bias, zero_cols):
+    """dW = dy^T x (and the bias gradient, the column sums of dy) through the grouped end-of-pass launch, if this backward pass may
+    postpone them (see set_deferred_reductions): returns (dw f32 [N, K], db f32 [N] or None) -- tensors that are FILLED when the pass
+    ends -- or None = launch now.  The operands stay referenced by the queue until then."""
+    M, N = dy.shape
+    K = x.shape[1]
+    if not (GROUPED_WGRAD and _ReduceQueue.enabled and dy.dtype == torch.bfloat16 and gemm_tn_ring_splits(M, N, K) > 0):
+        return None
+    q = _deferring((weight, bias))
+    if q is None:
+        return None
+    splits = grouped_wgrad_splits(M)
+    x = x.contiguous()
+    slot = grad_slot(weight)
+    dev = x.device
+    out = slot if slot is not None else torch.empty(N * K, dtype=torch.float32, device=dev)
+    if splits == 1:
+        part = out                                        # the finished f32 gradient straight from the kernel: nothing to reduce
+    else:
+        part = torch.empty(splits, N, K, dtype=torch.bfloat16 if GEMM_TN_RING_BF16 else torch.float32, device=dev)
+        q["jobs"].append((part, 0, dtype_code(part), splits, N * K, N * K, out))
+    dbp = db = None
+    if bias is not None:
+        db = torch.empty(N, dtype=torch.float32, device=dev)
+        dbp = db if splits == 1 else torch.empty(splits, N, dtype=torch.float32, device=dev)
+        if splits > 1:
+            q["jobs"].append((dbp, 0, F32, splits, N, N, db))
+        db = db.view(N)                                   # fresh views: see sum_rows
+    zlo, zhi = (0, 0) if zero_cols is None else (int(zero_cols[0]), int(zero_cols[1]))
+    q["wgrad_jobs"].append((dy, x, part, dbp, M, N, K, splits, zlo, zhi))
+    return out.view(N, K), db
+
+
 def gemm_tn_ring_splits(M, N, K):
-    """Row splits for pswin_gemm_tn_ring on dy [M, N], x [M, K] (one workgroup per CU and launch), or 0 = not for this shape."""
+    """Row splits for pswin_gemm_tn_ring on dy [M, N], x [M, K], or 0 = not for this shape.  ONE rule per configuration, whether the
+    product is launched alone or inside the grouped launch (the two modes then run the same arithmetic: the deferred step stays bit-equal
+    to the immediate one): about GROUPED_WGRAD_ROWS rows per workgroup by default; with PSWIN_GROUPED_WGRAD=0 the round-3 rule, one
+    workgroup per CU and launch."""
     if not GEMM_TN_RING or M < 512 or not bool(_lib.load().pswin_gemm_tn_ring_supported(M, N, K)):
         return 0
+    if GROUPED_WGRAD:
+        return grouped_wgrad_splits(M)
     return int(_lib.load().pswin_gemm_tn_ring_splits(M, N, K, GEMM_TN_RING_WGS))
 
 
@@ -862,6 +936,9 @@ def linear_backward(x, wb, dy, weight, bias, zero_bias_cols, need_dx, wbt=None):
         else:
             with _lib.timed("lib_gemm_dgrad", 2 * (M * K + M * N + N * K), 2 * M * K * N):
                 dx = dy @ wb
+    queued = queue_weight_gradient(dy, x, weight, bias, zero_bias_cols)
+    if queued is not None:
+        return dx, queued[0], queued[1]
     sp = 0
     rs = gemm_tn_ring_splits(M, N, K) if dy.dtype == torch.bfloat16 else 0
     db_part = None

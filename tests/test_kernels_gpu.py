@@ -825,6 +825,88 @@ def test_linear_on_the_tiled_gemm_matches_the_library_path(ops):
         assert torch.allclose(u, v, rtol=2e-2, atol=2e-2 * float(v.abs().max()))
 
 
+def test_gemm_tn_ring_jobs_one_launch_equals_the_single_launches(ops):
+    """pswin_gemm_tn_ring_jobs (round 4): many independent weight gradients in one launch per tile geometry.  Eleven jobs of all three
+    geometries, ragged M, 1 .. 40 splits, f32 and bf16 slabs, with and without bias sums / zero ranges, listed in an arbitrary order
+    (first_wg padding to multiples of 8, the binary search over the job table, longest-first ordering on the Python side are all in
+    play): every partial slab and bias partial must equal the single launch of the same product BIT FOR BIT, and the sums an fp32 matmul."""
+    import ctypes
+    from panoswintransformerobjectdetection_amd import _lib
+    lib = _lib.load()
+    torch.manual_seed(7)
+    spec = [(19600, 1152, 384, 9, True, True), (4096, 768, 3072, 2, True, False), (1470, 2304, 768, 1, False, True), (333, 192, 192, 3, False, False),
+            (68894, 288, 96, 34, True, True), (65536, 96, 384, 32, True, False), (1000, 288, 96, 1, False, True), (130, 48, 96, 2, True, False),
+            (5000, 192, 576, 40, True, True), (64, 192, 192, 1, False, False), (16384, 384, 1536, 8, True, True)]
+    jobs, singles = [], []
+    for M, N, K, sp, bf, with_bias in spec:
+        dy = torch.randn(M, N, device=DEV).to(torch.bfloat16)
+        x = torch.randn(M, K, device=DEV).to(torch.bfloat16)
+        pdt = torch.bfloat16 if bf else torch.float32
+        zc = (N // 3 // 16 * 16, 2 * (N // 3) // 16 * 16) if with_bias else None
+        if with_bias:
+            part1, db1 = ops.gemm_tn_ring(dy, x, sp, pdt, bias_sums=True, zero_cols=zc)
+        else:
+            part1, db1 = ops.gemm_tn_ring(dy, x, sp, pdt), None
+        part = torch.full_like(part1, float("nan"))
+        dbp = torch.full_like(db1, float("nan")) if with_bias else None
+        jobs.append((dy, x, part, dbp, M, N, K, sp, zc[0] if zc else 0, zc[1] if zc else 0))
+        singles.append((part1, db1))
+    ops._launch_wgrads(jobs)
+    torch.cuda.synchronize()
+    for (dy, x, part, dbp, M, N, K, sp, zlo, zhi), (part1, db1) in zip(jobs, singles):
+        assert torch.equal(part, part1), (M, N, K, sp)
+        if dbp is not None:
+            assert torch.equal(dbp, db1), (M, N, K, sp)
+        ref = dy.float().t() @ x.float()
+        assert torch.allclose(part.float().sum(0), ref, rtol=6e-3, atol=6e-3 * float(ref.abs().max()))
+    # argument errors never launch
+    bad = (_lib.TnJob * 1)()
+    bad[0].dy, bad[0].x, bad[0].partial, bad[0].M, bad[0].N, bad[0].K, bad[0].splits, bad[0].partial_dtype = 16, 16, 16, 4096, 200, 192, 1, 0
+    assert lib.pswin_gemm_tn_ring_jobs(ctypes.cast(bad, ctypes.c_void_p), 1, None) != 0
+    assert lib.pswin_gemm_tn_ring_jobs(None, 1, None) != 0
+
+
+def test_grouped_weight_gradients_are_bit_equal_to_immediate_ones(ops):
+    """ops.queue_weight_gradient: with deferred reductions a Linear's weight (and bias) gradient is produced by the grouped end-of-pass
+    launch; same split rule, kernel and summation order as the launch-where-produced mode, so the two agree bit for bit, and both with
+    fp32 autograd of the same bf16 operands."""
+    from panoswintransformerobjectdetection_amd.backbone import _linear
+    torch.manual_seed(3)
+    lins = [torch.nn.Linear(192, 576).to(DEV), torch.nn.Linear(576, 192).to(DEV), torch.nn.Linear(192, 384, bias=False).to(DEV)]
+    x = torch.randn(9000, 192, device=DEV)
+
+    def run():
+        for l in lins:
+            for p in l.parameters():
+                p.grad = None
+        h = _linear(x, lins[0], torch.bfloat16)
+        h = _linear(h, lins[1], torch.bfloat16)
+        h = _linear(h, lins[2], torch.bfloat16)
+        h.float().square().mean().backward()
+        return [p.grad.detach().clone() for l in lins for p in l.parameters()]
+
+    assert ops.GROUPED_WGRAD and ops.gemm_tn_ring_splits(9000, 576, 192) == ops.grouped_wgrad_splits(9000) == 4
+    prev = ops.set_deferred_reductions(False)
+    try:
+        ref = run()
+        ops.set_deferred_reductions(True)
+        got = run()
+    finally:
+        ops.set_deferred_reductions(prev)
+    assert not ops._ReduceQueue.tasks
+    for a, b in zip(ref, got):
+        assert torch.isfinite(b).all() and torch.equal(a, b)
+    # against autograd on fp32 copies of the bf16-rounded operands (loose: bf16 activations in between)
+    xs = x.to(torch.bfloat16).float()
+    ws = [l.weight.detach().to(torch.bfloat16).float().requires_grad_(True) for l in lins]
+    h = (xs @ ws[0].t() + lins[0].bias.detach().to(torch.bfloat16).float()).to(torch.bfloat16).float()
+    h = (h @ ws[1].t() + lins[1].bias.detach().to(torch.bfloat16).float()).to(torch.bfloat16).float()
+    h = (h @ ws[2].t()).to(torch.bfloat16).float()
+    h.square().mean().backward()
+    for w, l in zip(ws, lins):
+        assert float((l.weight.grad - w.grad).norm() / w.grad.norm()) < 2e-2
+
+
 @pytest.mark.parametrize("M,N,K,splits", [(19600, 1152, 384, 0), (16384, 384, 1536, 0), (4096, 768, 3072, 7), (5880, 2304, 768, 0),
                                           (74480, 576, 192, 0), (74480, 192, 192, 0), (333, 192, 192, 3), (64, 192, 192, 1), (130, 384, 192, 2),
                                           (1000, 384, 384, 15), (4033, 192, 576, 63),
