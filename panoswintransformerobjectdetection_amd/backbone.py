@@ -17,8 +17,9 @@ configuration of PatchEmbed uses MIOpen convolutions.  uv coordinates never ride
 (the reference's C+2 layout, HOT:964): they are a function of position, so the great-circle tables are cached
 per shape.
 
-Unsupported on purpose (raises, never falls back): CPU tensors, window_size != 7, head_dim != 32,
-drop_rate / attn_drop_rate != 0 (every reference config sets them to 0), norm_layer other than LayerNorm.
+Raises, never falls back: CPU tensors, norm_layer other than LayerNorm.  Options the kernels are not specialised for --
+window_size != 7, head_dim != 32, drop_rate / attn_drop_rate != 0 (no configuration in the reference tree uses one) -- run their window
+blocks as plain torch ops on the GPU (fallback.py) and say so with a warning at construction.
 """
 import math
 import warnings
@@ -28,7 +29,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 import torch.utils.checkpoint as checkpoint
 
-from . import geometry, ops, stem
+from . import fallback, geometry, ops, stem
 from ._lib import HEAD_DIM, WS, WTOK, PswinError
 from .registry import BACKBONES
 
@@ -104,11 +105,12 @@ class Mlp(nn.Module):
 class WindowAttention(nn.Module, DoubleModeModule):
     """Parameter holder of BasicWindowAttention / WindowAttention (HOT:211-323)."""
 
-    def __init__(self, dim, window_size, num_heads, qkv_bias=True, qk_scale=None, separate_qkv=False):
+    def __init__(self, dim, window_size, num_heads, qkv_bias=True, qk_scale=None, separate_qkv=False, generic=False):
         super().__init__()
-        if dim % num_heads or dim // num_heads != HEAD_DIM:
-            raise PswinError(f"the MI355X attention kernel is specialised for head_dim == {HEAD_DIM}, got dim={dim}, "
-                             f"heads={num_heads}")
+        assert dim % num_heads == 0, "dim must be divisible by num_heads"           # HOT:284
+        if not generic and (dim // num_heads != HEAD_DIM or window_size != WS):
+            raise PswinError(f"the MI355X attention kernels are specialised for head_dim == {HEAD_DIM} and window_size == {WS}, got "
+                             f"dim={dim}, heads={num_heads}, window_size={window_size}")
         self.dim, self.num_heads = dim, num_heads
         self.scale = qk_scale or (dim // num_heads) ** -0.5
         self.register_buffer("relative_position_index_OO", _relative_position_index(window_size))
@@ -125,12 +127,15 @@ class PanoSwinTransformerBlock(nn.Module, DoubleModeModule):
     """HOT:412-536."""
 
     def __init__(self, dim, num_heads, window_size=7, shift_size=0, mlp_ratio=4., qkv_bias=True, qk_scale=None,
-                 drop_path=0., pano_mode=True):
+                 drop_path=0., pano_mode=True, drop=0., attn_drop=0.):
         super().__init__()
         assert 0 <= shift_size < window_size, "shift_size must in 0-window_size"
         self.dim, self.num_heads, self.shift_size, self.drop_path_p = dim, num_heads, shift_size, float(drop_path)
+        self.window_size, self.drop, self.attn_drop = window_size, float(drop), float(attn_drop)
+        # the options the HIP kernels are not specialised for: this block then runs as plain torch ops (fallback.py)
+        self.generic = window_size != WS or dim // num_heads != HEAD_DIM or self.drop > 0. or self.attn_drop > 0.
         self.norm1 = nn.LayerNorm(dim)
-        self.attn = WindowAttention(dim, window_size, num_heads, qkv_bias, qk_scale)
+        self.attn = WindowAttention(dim, window_size, num_heads, qkv_bias, qk_scale, generic=self.generic)
         self.norm2 = nn.LayerNorm(dim)
         self.mlp = Mlp(dim, int(dim * mlp_ratio))
         self.pano_mode = pano_mode
@@ -140,6 +145,9 @@ class PanoSwinTransformerBlock(nn.Module, DoubleModeModule):
         SimplePanoSwinTransformer.forward) or None: draw them here."""
         B, S, C = x.shape
         assert S == H * W, "input feature has wrong size"
+        if self.generic:                          # window_size != 7 / head_dim != 32 / dropout: plain torch ops (SURVEY 8c)
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=(cd == torch.bfloat16 and x.is_cuda)):
+                return fallback.block_forward(self, x, H, W, self.attn_drop, self.drop).float()
         dev = x.device
         pano = bool(self.pano_mode)
         wmap, inv, nW = ops.window_maps(pano, H, W, self.shift_size, dev)
@@ -266,13 +274,16 @@ class BasicLayer(nn.Module, DoubleModeModule):
     """HOT:579-724."""
 
     def __init__(self, dim, depth, num_heads, window_size=7, mlp_ratio=4., qkv_bias=True, qk_scale=None,
-                 drop_path=0., downsample=None, use_checkpoint=False, pano_mode=True):
+                 drop_path=0., downsample=None, use_checkpoint=False, pano_mode=True, drop=0., attn_drop=0.):
         super().__init__()
         self.use_checkpoint = use_checkpoint
         blocks = [PanoSwinTransformerBlock(dim, num_heads, window_size, 0 if i % 2 == 0 else window_size // 2,
                                            mlp_ratio, qkv_bias, qk_scale,
-                                           drop_path[i] if isinstance(drop_path, list) else drop_path, pano_mode)
+                                           drop_path[i] if isinstance(drop_path, list) else drop_path, pano_mode, drop, attn_drop)
                   for i in range(depth - depth % 2)]
+        if depth % 2 and blocks and blocks[0].generic:
+            raise PswinError("an odd stage depth appends a PitchAttentionModule (HOT:636-647), which has no generic form: window_size == 7, "
+                             "head_dim == 32 and dropout 0 are required for it")
         if depth % 2:
             blocks.append(PitchAttentionModule(dim, num_heads, window_size, qkv_bias, qk_scale, mlp_ratio,
                                                pano_mode=pano_mode))
@@ -411,11 +422,15 @@ class SimplePanoSwinTransformer(nn.Module, DoubleModeModule):
                  drop_path_rate=0.2, norm_layer=nn.LayerNorm, ape=False, patch_norm=True, out_indices=(0, 1, 2, 3),
                  frozen_stages=-1, use_checkpoint=False, pano_mode=True, compute_dtype=torch.float32):
         super().__init__()
-        if window_size != WS:
-            raise PswinError(f"the MI355X kernels are specialised for window_size == {WS}, got {window_size}")
-        if drop_rate != 0. or attn_drop_rate != 0.:
-            raise PswinError("drop_rate / attn_drop_rate must be 0 (as in every reference config); only DropPath is "
-                             "implemented")
+        self.drop_rate = float(drop_rate)
+        generic = [f"window_size={window_size}"] if window_size != WS else []
+        generic += [f"head_dim={embed_dim // num_heads[0]}"] if embed_dim // num_heads[0] != HEAD_DIM else []
+        generic += [f"drop_rate={drop_rate}"] if drop_rate else []
+        generic += [f"attn_drop_rate={attn_drop_rate}"] if attn_drop_rate else []
+        if generic:
+            warnings.warn("SimplePanoSwinTransformer: " + ", ".join(generic) + " is outside what the MI355X kernels are specialised for "
+                          "(window 7, head_dim 32, dropout 0: every configuration of the reference tree); the window blocks of this model "
+                          "run as plain torch ops on the GPU (fallback.py), not on the hand-written kernels")
         if norm_layer is not nn.LayerNorm and norm_layer != "LN" and norm_layer is not None:
             raise PswinError("norm_layer must be nn.LayerNorm")
         if isinstance(compute_dtype, str):
@@ -435,7 +450,7 @@ class SimplePanoSwinTransformer(nn.Module, DoubleModeModule):
             self.layers.append(BasicLayer(int(embed_dim * 2 ** i), depths[i], num_heads[i], window_size, mlp_ratio,
                                           qkv_bias, qk_scale, dpr[sum(depths[:i]):sum(depths[:i + 1])],
                                           PatchMerging if i < self.num_layers - 1 else None, use_checkpoint,
-                                          pano_mode))
+                                          pano_mode, drop_rate, attn_drop_rate))
         self.num_features = [int(embed_dim * 2 ** i) for i in range(self.num_layers)]
         for i in out_indices:
             self.add_module(f"norm{i}", nn.LayerNorm(self.num_features[i]))
@@ -583,6 +598,8 @@ class SimplePanoSwinTransformer(nn.Module, DoubleModeModule):
         if self.pano_mode and self.ape:
             feat = ops.abs_pos_features(Wh, Ww, x.device)                               # HOT:926-934
             x = _ApeAdd.apply(x, feat, self.abs_encoder.weight, self.abs_encoder.bias)
+        if self.drop_rate > 0.:
+            x = F.dropout(x, self.drop_rate, self.training)                              # pos_drop (HOT:967), features only
         outs = []
         dp_all = self._draw_drop_path(x) if self.training else None
         for i, layer in enumerate(self.layers):

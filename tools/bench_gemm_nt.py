@@ -41,6 +41,11 @@ shapes = [("m1 red", 65536, 384, 192, 1), ("s1 qkv", 74480, 192, 576, 2), ("s1 p
           ("s1 fc2", 65536, 768, 192, 2), ("m2 red", 16384, 768, 384, 1), ("s2 qkv", 19600, 384, 1152, 6), ("s2 proj", 19600, 384, 384, 6),
           ("s2 fc1", 16384, 384, 1536, 6), ("s2 fc2", 16384, 1536, 384, 6), ("m3 red", 4096, 1536, 768, 1), ("s3 qkv", 5880, 768, 2304, 2),
           ("s3 proj", 5880, 768, 768, 2), ("s3 fc1", 4096, 768, 3072, 2), ("s3 fc2", 4096, 3072, 768, 2)]
+if len(sys.argv) > 1:                     # python tools/bench_gemm_nt.py <batch>: the same shapes at another batch size (rows scale with it)
+    _b = int(sys.argv[1])
+    shapes = [(n, M * _b // 8, K, N, c) for n, M, K, N, c in shapes]
+
+
 def main():
     tot = {"lib_fwd": 0.0, "hip_fwd": 0.0, "ring_fwd": 0.0, "lib_dgrad": 0.0, "hip_dgrad": 0.0, "ring_dgrad": 0.0, "floor": 0.0}
     print(f"{'':8s} {'M':>6s} {'K':>5s} {'N':>5s} | fwd: lib  hip64 hip128   ring | dgrad: lib  hip64 hip128   ring | floor us | x count")
