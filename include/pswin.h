@@ -138,6 +138,17 @@ int pswin_ln_gather_bwd(const void* dy, int dy_dtype, const int32_t* inv, const 
                         float* dres_sum, void* dx, float* dgamma, float* dbeta, float* workspace, int B, int S, int n_out,
                         int C, void* stream);
 
+/* pswin_ln_gather_bwd with a second output (round 4): ex[b][ex_map ? ex_map[t] : t] = bf16(ex_scale[b] * dx[b][t]) for every token, zero
+ * rows at the ex_pads slots of every image -- the backward of the pswin_window_scatter_add that fed this LayerNorm's input (gather of the
+ * residual-stream gradient into window order, or the plain bf16 cast of the Mlp branch), written while dx is in registers instead of by
+ * pswin_window_gather re-reading it.  ex: bf16 [B, ex_rows, C]; ex_map: int32 [S] (token -> slot) or NULL (identity, ex_rows == S);
+ * ex_pads: int32 [n_ex_pads = ex_rows - S] the slots no token maps to; ex_scale: f32 [B] or NULL.  x_dtype f32, C <= 1024.
+ * ex == NULL: pswin_ln_gather_bwd. */
+int pswin_ln_gather_bwd_ex(const void* dy, int dy_dtype, const int32_t* inv, const void* x, int x_dtype, const float* mean,
+                           const float* rstd, const float* gamma, const float* dres, const float* res_scale, float* dres_sum, void* dx,
+                           float* dgamma, float* dbeta, float* workspace, int B, int S, int n_out, int C, void* ex, const int32_t* ex_map,
+                           int ex_rows, const float* ex_scale, const int32_t* ex_pads, int n_ex_pads, void* stream);
+
 /* window_scatter_add followed at once by a token-order LayerNorm (the attention half of a block, HOT:516-536:
  * x1 = shortcut + DropPath(window_reverse(proj out) + proj bias), then norm2(x1)) in ONE pass:
  *   x1[b][t] = resid[b][t] + scale[b] * (win[b][inv[t]] + bias);   y[b][t] = LN(x1[b][t]) * gamma + beta
@@ -148,6 +159,16 @@ int pswin_ln_gather_bwd(const void* dy, int dy_dtype, const int32_t* inv, const 
 int pswin_scatter_add_ln_fwd(const void* win, int win_dtype, const int32_t* inv, const float* resid, const float* scale,
                              const float* bias, float* x1, const float* gamma, const float* beta, float eps, void* y,
                              int y_dtype, float* mean, float* rstd, int B, int S, int n_slots, int C, void* stream);
+
+/* The same pass with the normalised rows written through a token -> slot map (round 4): y[b][out_map[t]] = LN(x1[b][t]) ..., zero rows at
+ * the out_pads slots -- the residual add that ends a block (x + DropPath(mlp)) fused with the NEXT block's norm1 + shift + pad + window
+ * partition (HOT:534-536 then HOT:503-513 of the following block): the new residual stream is written once and not re-read by a
+ * LayerNorm + gather kernel.  y: [B, n_out, C]; out_map: int32 [S] or NULL (then n_out == S: pswin_scatter_add_ln_fwd);
+ * out_pads: int32 [n_out_pads = n_out - S]. */
+int pswin_scatter_add_ln_fwd_map(const void* win, int win_dtype, const int32_t* inv, const float* resid, const float* scale,
+                                 const float* bias, float* x1, const float* gamma, const float* beta, float eps, void* y, int y_dtype,
+                                 float* mean, float* rstd, int B, int S, int n_slots, int C, const int32_t* out_map, int n_out,
+                                 const int32_t* out_pads, int n_out_pads, void* stream);
 
 /* Output norms: y = LayerNorm(x) written channel-major, i.e. norm{i}(x).view(B, H, W, C).permute(0, 3, 1, 2).contiguous()
  * of HOT:975-977 in one pass (x: f32 [B, S, C]; y: f32 [B, C, S]; mean, rstd: f32 [B, S]), and its backward from the

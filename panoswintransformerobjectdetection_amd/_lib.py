@@ -30,7 +30,10 @@ _PROTOTYPES = {
     "pswin_window_scatter_add": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "pswin_ln_gather_fwd": [_vp, _i, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     "pswin_ln_gather_bwd": [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "pswin_ln_gather_bwd_ex": [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i,
+                               _vp],
     "pswin_scatter_add_ln_fwd": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
+    "pswin_scatter_add_ln_fwd_map": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp],
     "pswin_ln_nchw_supported": [_i, _i],
     "pswin_ln_nchw_fwd": [_vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _vp],
     "pswin_ln_nchw_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],

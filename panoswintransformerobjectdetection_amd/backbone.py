@@ -140,15 +140,21 @@ class PanoSwinTransformerBlock(nn.Module, DoubleModeModule):
         self.mlp = Mlp(dim, int(dim * mlp_ratio))
         self.pano_mode = pano_mode
 
-    def forward(self, x, H, W, cd, dp_scales=None):
+    def forward(self, x, H, W, cd, dp_scales=None, pre=None, nxt=None, nxt_scales=None):
         """dp_scales: this block's two DropPath factor vectors ([2, B], from one batched draw for the whole network, see
-        SimplePanoSwinTransformer.forward) or None: draw them here."""
-        B, S, C = x.shape
+        SimplePanoSwinTransformer.forward) or None: draw them here.
+        pre: (win, x) = this block's norm1 + shift + pad + partition already done by the previous block's closing kernel.
+        nxt (+ nxt_scales): the next block of the stage if this block's closing residual add should also run ITS norm1 + partition
+        (ops.scatter_add_layer_norm(out=...)); the return value is then that block's `pre` instead of the residual stream."""
+        if pre is None:
+            B, S, C = x.shape
+        else:
+            B, S, C = pre[1].shape
         assert S == H * W, "input feature has wrong size"
         if self.generic:                          # window_size != 7 / head_dim != 32 / dropout: plain torch ops (SURVEY 8c)
             with torch.autocast("cuda", dtype=torch.bfloat16, enabled=(cd == torch.bfloat16 and x.is_cuda)):
                 return fallback.block_forward(self, x, H, W, self.attn_drop, self.drop).float()
-        dev = x.device
+        dev = x.device if pre is None else pre[1].device
         pano = bool(self.pano_mode)
         wmap, inv, nW = ops.window_maps(pano, H, W, self.shift_size, dev)
         if pano:
@@ -161,14 +167,13 @@ class PanoSwinTransformerBlock(nn.Module, DoubleModeModule):
         # bf16 path: the proj / fc2 biases ride on the residual row kernels and fc1's on the GELU kernel (no GEMM
         # epilogues, no column-sum passes for their gradients); fp32 (parity) path: plain F.linear with bias
         fuse = cd != torch.float32
-        if dp_scales is not None and self.drop_path_p > 0.0 and self.training:
-            s1, s2 = dp_scales[0], dp_scales[1]
+        s1, s2 = self.drop_path_scales(x if pre is None else pre[1], dp_scales)
+        if pre is not None:
+            win, x = pre
         else:
-            s1 = _drop_path_scale(x, self.drop_path_p, self.training)             # HOT:533: one draw per branch
-            s2 = _drop_path_scale(x, self.drop_path_p, self.training)             # HOT:536
-        # the second result is x itself: using it for the shortcut folds the shortcut's gradient into the LN backward kernel
-        win, x = ops.layer_norm_gather(x, n1.weight, n1.bias, n1.eps, wmap, inv, cd, passthrough=True,
-                                       res_bias=a.proj.bias if fuse else None, res_scale=s1)   # [B, nW*49, C]
+            # the second result is x itself: using it for the shortcut folds the shortcut's gradient into the LN backward kernel
+            win, x = ops.layer_norm_gather(x, n1.weight, n1.bias, n1.eps, wmap, inv, cd, passthrough=True,
+                                           res_bias=a.proj.bias if fuse else None, res_scale=s1)   # [B, nW*49, C]
         # the K third of d(qkv) sums to zero over every window (rows of dS sum to 0): its bias gradient is not summed
         if fuse and ops.FUSED_WINDOW_ATTENTION and ops.window_attention_fused_supported(win.view(-1, C), a.num_heads):
             # C = 96: qkv Linear, attention and proj Linear of a window in one kernel, weights resident in LDS
@@ -184,16 +189,38 @@ class PanoSwinTransformerBlock(nn.Module, DoubleModeModule):
             att = _linear(att, a.proj, cd, use_bias=not fuse).view(B, nW * WTOK, C)
         n2 = self.norm2
         if x.dtype == torch.float32 and C <= 1024:
-            # shortcut + DropPath(attn) and norm2 of the sum in one kernel (the sum is not read back by a LayerNorm pass)
+            # shortcut + DropPath(attn) and norm2 of the sum in one kernel (the sum is not read back by a LayerNorm pass); its backward
+            # kernel also writes the window gather of the shortcut sum's gradient (in_pads: the zero slots of this block's map)
             h, x = ops.scatter_add_layer_norm(att, x, wmap, inv, s1, a.proj.bias if fuse else None, n2.weight, n2.bias,
-                                              n2.eps, cd, res_bias=self.mlp.fc2.bias if fuse else None, res_scale=s2)
+                                              n2.eps, cd, res_bias=self.mlp.fc2.bias if fuse else None, res_scale=s2,
+                                              in_pads=ops.window_pads(pano, H, W, self.shift_size, dev))
         else:
             x = ops.window_scatter_add(att, x, wmap, inv, s1, a.proj.bias if fuse else None, True)
             h, x = ops.layer_norm_gather(x, n2.weight, n2.bias, n2.eps, out_dtype=cd, passthrough=True,
                                          res_bias=self.mlp.fc2.bias if fuse else None, res_scale=s2)
         y = self.mlp.forward_nobias2(h, cd) if fuse else self.mlp(h, cd)
-        ident = ops.identity_map(S, dev)                                          # x + DropPath(mlp): one row kernel
-        return ops.window_scatter_add(y, x, ident, ident, s2, self.mlp.fc2.bias if fuse else None, True)
+        ident = ops.identity_map(S, dev)
+        if nxt is not None:
+            # x + DropPath(mlp) AND the next block's norm1 + shift + pad + partition in one kernel: (its windows, the new residual stream)
+            npano = bool(nxt.pano_mode)
+            _, inv_n, nW_n = ops.window_maps(npano, H, W, nxt.shift_size, dev)
+            s1n = nxt.drop_path_scales(x, nxt_scales)[0]
+            return ops.scatter_add_layer_norm(y, x, ident, None, s2, self.mlp.fc2.bias, nxt.norm1.weight, nxt.norm1.bias, nxt.norm1.eps, cd,
+                                              res_bias=nxt.attn.proj.bias, res_scale=s1n,
+                                              out=(inv_n, nW_n * WTOK, ops.window_pads(npano, H, W, nxt.shift_size, dev)))
+        return ops.window_scatter_add(y, x, ident, ident, s2, self.mlp.fc2.bias if fuse else None, True)   # x + DropPath(mlp): one row kernel
+
+    def drop_path_scales(self, x, dp_scales):
+        """(s1, s2): the two per-sample DropPath factor vectors of this block (HOT:533, 536), from the batched draw or drawn here"""
+        if dp_scales is not None and self.drop_path_p > 0.0 and self.training:
+            return dp_scales[0], dp_scales[1]
+        return _drop_path_scale(x, self.drop_path_p, self.training), _drop_path_scale(x, self.drop_path_p, self.training)
+
+    def joins_with(self, nxt, cd, dp_scales_given, C):
+        """may this block's closing residual add also run `nxt`'s norm1 + partition?  bf16 path, fp32 residual stream, both blocks on the
+        kernels, and the next block's DropPath factors known here (batched draw, or no DropPath to draw)"""
+        return (ops.LN_FUSED_MOVES and isinstance(nxt, PanoSwinTransformerBlock) and not self.generic and not nxt.generic and cd != torch.float32
+                and C <= 1024 and (dp_scales_given or nxt.drop_path_p == 0.0 or not nxt.training))
 
 
 class PitchAttentionModule(WindowAttention):
@@ -298,14 +325,22 @@ class BasicLayer(nn.Module, DoubleModeModule):
 
     def forward(self, x, H, W, cd, out_norm=None, dp_scales=None):
         """-> (stage output [normed by out_norm if given], H, W, input of the next stage, its H, W)"""
+        pre = None
         for i, blk in enumerate(self.blocks):
-            extra = ()
-            if dp_scales is not None and isinstance(blk, PanoSwinTransformerBlock):
-                extra = (dp_scales[i],)
-            if self.use_checkpoint:
-                x = checkpoint.checkpoint(blk, x, H, W, cd, *extra, use_reentrant=False)
+            is_blk = isinstance(blk, PanoSwinTransformerBlock)
+            sc = dp_scales[i] if (dp_scales is not None and is_blk) else None
+            if self.use_checkpoint or not is_blk:
+                x = checkpoint.checkpoint(blk, x, H, W, cd, *(() if sc is None else (sc,)), use_reentrant=False) if self.use_checkpoint \
+                    else blk(x, H, W, cd)
+                continue
+            nxt = self.blocks[i + 1] if i + 1 < len(self.blocks) else None
+            if nxt is not None and not blk.joins_with(nxt, cd, dp_scales is not None, x.shape[-1] if pre is None else pre[1].shape[-1]):
+                nxt = None
+            out = blk(x, H, W, cd, sc, pre, nxt, dp_scales[i + 1] if (nxt is not None and dp_scales is not None) else None)
+            if nxt is not None:
+                pre, x = out, None
             else:
-                x = blk(x, H, W, cd, *extra)
+                pre, x = None, out
         y = x
         if out_norm is not None:                    # output norm first: the downsample branch's gradient then joins
             if self.downsample is not None:         # the stream inside the norm's backward kernel; NCHW written directly

@@ -126,6 +126,24 @@ __global__ __launch_bounds__(THREADS) void ln_fwd_kernel(const void* __restrict_
     }
 }
 
+// optional destination map of ln_add_fwd_kernel's normalised rows: token t of image b -> y row b * n_out + map[t]; pads = the slots of an
+// image no token maps to (zero rows).  map == nullptr: token order (row = b * S + t).
+struct OutMap {
+    const int32_t* map;
+    const int32_t* pads;
+    int n_out, n_pads, B;
+};
+// optional second output of ln_bwd_kernel (MODE 0): ex[b][map ? map[t] : t] = bf16(scale[b] * dx[b][t]), zero rows at the pad slots --
+// the window gather (or plain cast) that turns the residual-stream gradient into the branch gradient the next backward kernel reads
+// (window_scatter_add's backward), written while dx is in registers instead of by a pass of its own
+struct BwdExtra {
+    void* ex;
+    const int32_t* map;
+    const float* scale;
+    const int32_t* pads;
+    int n_rows, n_pads, B;
+};
+
 // window_scatter_add + LayerNorm in token order, one pass (the attention half of a block ends with
 // x1 = x + DropPath(window_reverse(proj(.)) + b) and norm2(x1) follows at once, HOT:516-536):
 //   x1[b][t] = resid[b][t] + scale[b] * (win[b][inv[t]] + bias);   y[b][t] = LN(x1[b][t]) * gamma + beta
@@ -138,14 +156,29 @@ __global__ __launch_bounds__(THREADS) void ln_add_fwd_kernel(const void* __restr
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float eps, void* __restrict__ y, float* __restrict__ mean,
                                                              float* __restrict__ rstd, long long rows, int S, int n_slots,
-                                                             int C) {
+                                                             int C, OutMap om) {
     constexpr int RPB = THREADS / L;
     const int lane = threadIdx.x % L;
     const long long row = (long long)blockIdx.x * RPB + threadIdx.x / L;
-    if (row >= rows) return;
+    const int nchunks = C / 4;
+    if (row >= rows) {
+        // round 4: y may be written through a token -> slot map (the norm1 + shift + pad + partition of the NEXT block fused into the
+        // residual add that ends this one); the slots no token maps to are zero rows, written by the row groups behind the last token
+        const long long p = row - rows;
+        if (om.map && p < (long long)om.n_pads * om.B) {
+            const int b = (int)(p / om.n_pads);
+            const size_t yrow = (size_t)b * om.n_out + om.pads[p - (long long)b * om.n_pads];
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                const int ch = lane + k * L;
+                if (ch < nchunks) store4<YDT>(y, yrow * C + 4 * (size_t)ch, f32x4{0.f, 0.f, 0.f, 0.f});
+            }
+        }
+        return;
+    }
     const int b = (int)(row / S);
     const int t = (int)(row - (long long)b * S);
-    const int nchunks = C / 4;
+    const size_t yrow = om.map ? (size_t)b * om.n_out + om.map[t] : (size_t)row;
     const size_t wrow = ((size_t)b * n_slots + (inv ? inv[t] : t)) * C;
     const float sc = scale ? scale[b] : 1.0f;
     f32x4 v[NCH];
@@ -181,7 +214,7 @@ __global__ __launch_bounds__(THREADS) void ln_add_fwd_kernel(const void* __restr
         if (ch < nchunks) {
             const f32x4 g4 = *reinterpret_cast<const f32x4*>(gamma + 4 * ch);
             const f32x4 b4 = *reinterpret_cast<const f32x4*>(beta + 4 * ch);
-            store4<YDT>(y, (size_t)row * C + 4 * (size_t)ch, (v[k] - mu) * rs_ * g4 + b4);
+            store4<YDT>(y, yrow * C + 4 * (size_t)ch, (v[k] - mu) * rs_ * g4 + b4);
         }
     }
     if (lane == 0) {
@@ -194,15 +227,15 @@ __global__ __launch_bounds__(THREADS) void ln_add_fwd_kernel(const void* __restr
 // scatters the 4 quarters of dx back to their tokens.  dgamma / dbeta: per-block partial sums, fixed order.
 // RSUM: also accumulate sum_rows res_scale[b] * dres[row] (the bias gradient of the Linear whose output, plus bias, was
 // added onto the residual stream through the shortcut this LayerNorm's input came along): third partial segment.
-template <int MODE, int DYDT, int XDT, int L, int NCH, bool RSUM>
-__global__ __launch_bounds__(THREADS) void ln_bwd_kernel(const void* __restrict__ dy, const int32_t* __restrict__ inv,
+template <int MODE, int DYDT, int XDT, int L, int NCH, bool RSUM, bool EX = false>
+__global__ __launch_bounds__(THREADS, (EX && NCH == 3) ? 4 : 1) void ln_bwd_kernel(const void* __restrict__ dy, const int32_t* __restrict__ inv,
                                                          const void* __restrict__ x, RowSrc rs,
                                                          const float* __restrict__ mean,
                                                          const float* __restrict__ rstd,
                                                          const float* __restrict__ gamma, void* __restrict__ dx,
                                                          const float* __restrict__ dres,
                                                          const float* __restrict__ res_scale, float* __restrict__ part,
-                                                         long long rows, int C) {
+                                                         long long rows, int C, BwdExtra ex = BwdExtra{}) {
     constexpr int RPB = THREADS / L;
     constexpr int NSEG = RSUM ? 3 : 2;
     __shared__ float red[2][THREADS * 4];      // [row group][lane][4 elements] of one chunk column at a time
@@ -224,6 +257,12 @@ __global__ __launch_bounds__(THREADS) void ln_bwd_kernel(const void* __restrict_
         const size_t img_in = (size_t)b * rs.S * (MODE == 0 ? C : C / 4);
         const float mu = mean[row], rs_ = rstd[row];
         const float rsc = (RSUM && res_scale) ? res_scale[b] : 1.0f;
+        [[maybe_unused]] unsigned ex_row = 0;                    // element offset of the extra output's row (the launcher checks < 2^31 elements)
+        [[maybe_unused]] float ex_sc = 1.0f;
+        if constexpr (EX) {
+            ex_row = ((unsigned)b * (unsigned)ex.n_rows + (unsigned)(ex.map ? ex.map[r] : r)) * (unsigned)C;
+            ex_sc = ex.scale ? ex.scale[b] : 1.0f;
+        }
         f32x4 xh[NCH], g[NCH], rv[NCH];
         long long offs[NCH];
         float s1 = 0.f, s2 = 0.f;
@@ -264,6 +303,19 @@ __global__ __launch_bounds__(THREADS) void ln_bwd_kernel(const void* __restrict_
                     if constexpr (RSUM) dr[k] = dr[k] + rv[k] * rsc;
                 }
                 store4<XDT>(dx, img_in + (size_t)offs[k], v);
+                if constexpr (EX) store4<PSWIN_BF16>(ex.ex, ex_row + 4u * (unsigned)ch, v * ex_sc);
+            }
+        }
+    }
+    if constexpr (EX) {             // the slots no token maps to: zero rows (what the separate window gather writes there)
+        const long long npad = (long long)ex.n_pads * ex.B;
+        for (long long p = (long long)blockIdx.x * RPB + rsub; p < npad; p += (long long)gridDim.x * RPB) {
+            const int b = (int)(p / ex.n_pads);
+            const size_t er = (size_t)b * ex.n_rows + ex.pads[p - (long long)b * ex.n_pads];
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                const int ch = lane + k * L;
+                if (ch < nchunks) store4<PSWIN_BF16>(ex.ex, er * C + 4 * (size_t)ch, f32x4{0.f, 0.f, 0.f, 0.f});
             }
         }
     }
@@ -550,21 +602,35 @@ int launch_fwd(int L, const void* x, const RowSrc& rs, const float* gamma, const
 template <int MODE, int DYDT, int XDT, bool RSUM>
 int launch_bwd(int L, const void* dy, const int32_t* inv, const void* x, const RowSrc& rs, const float* mean,
                const float* rstd, const float* gamma, void* dx, const float* dres, const float* res_scale, float* part,
-               long long rows, int C, int blocks, hipStream_t st) {
+               long long rows, int C, int blocks, hipStream_t st, BwdExtra ex = BwdExtra{}) {
+    constexpr bool CAN_EX = MODE == 0 && XDT == PSWIN_F32;
 #define PSWIN_LN_BWD(LL)                                                                                                \
     case LL:                                                                                                            \
+        if constexpr (CAN_EX) {                                                                                         \
+            if (ex.ex) {                                                                                                \
+                if (C / 4 <= 3 * LL)                                                                                    \
+                    hipLaunchKernelGGL((ln_bwd_kernel<MODE, DYDT, XDT, LL, 3, RSUM, true>), dim3(blocks), dim3(THREADS), 0, st, dy, inv, \
+                                       x, rs, mean, rstd, gamma, dx, dres, res_scale, part, rows, C, ex);               \
+                else                                                                                                    \
+                    hipLaunchKernelGGL((ln_bwd_kernel<MODE, DYDT, XDT, LL, 4, RSUM, true>), dim3(blocks), dim3(THREADS), 0, st, dy, inv, \
+                                       x, rs, mean, rstd, gamma, dx, dres, res_scale, part, rows, C, ex);               \
+                break;                                                                                                  \
+            }                                                                                                           \
+        }                                                                                                               \
         if (C / 4 <= 3 * LL)      /* 3 chunks per lane (C = 96, 192, 384, 768): 20 registers less, 4 waves per SIMD */      \
             hipLaunchKernelGGL((ln_bwd_kernel<MODE, DYDT, XDT, LL, 3, RSUM>), dim3(blocks), dim3(THREADS), 0, st, dy, inv, \
-                               x, rs, mean, rstd, gamma, dx, dres, res_scale, part, rows, C);                           \
+                               x, rs, mean, rstd, gamma, dx, dres, res_scale, part, rows, C, BwdExtra{});               \
         else                                                                                                            \
             hipLaunchKernelGGL((ln_bwd_kernel<MODE, DYDT, XDT, LL, 4, RSUM>), dim3(blocks), dim3(THREADS), 0, st, dy, inv, \
-                               x, rs, mean, rstd, gamma, dx, dres, res_scale, part, rows, C);                           \
+                               x, rs, mean, rstd, gamma, dx, dres, res_scale, part, rows, C, BwdExtra{});               \
         break;
     if (wide_row(C)) {
+        if (ex.ex) return PSWIN_ERR_UNSUPPORTED;
         hipLaunchKernelGGL((ln_bwd_kernel<MODE, DYDT, XDT, 64, 8, RSUM>), dim3(blocks), dim3(THREADS), 0, st, dy, inv, x, rs,
-                           mean, rstd, gamma, dx, dres, res_scale, part, rows, C);
+                           mean, rstd, gamma, dx, dres, res_scale, part, rows, C, BwdExtra{});
         PSWIN_LAUNCH_RET();
     }
+    if (ex.ex && !CAN_EX) return PSWIN_ERR_UNSUPPORTED;
     switch (L) {
         PSWIN_LN_BWD(2) PSWIN_LN_BWD(4) PSWIN_LN_BWD(8) PSWIN_LN_BWD(16) PSWIN_LN_BWD(32) PSWIN_LN_BWD(64)
         default: return PSWIN_ERR_ARG;
@@ -609,15 +675,19 @@ extern "C" int pswin_ln_gather_fwd(const void* x, int x_dtype, const int32_t* ma
     });
 }
 
-extern "C" int pswin_scatter_add_ln_fwd(const void* win, int win_dtype, const int32_t* inv, const float* resid,
-                                        const float* scale, const float* bias, float* x1, const float* gamma,
-                                        const float* beta, float eps, void* y, int y_dtype, float* mean, float* rstd, int B,
-                                        int S, int n_slots, int C, void* stream) {
+extern "C" int pswin_scatter_add_ln_fwd_map(const void* win, int win_dtype, const int32_t* inv, const float* resid,
+                                            const float* scale, const float* bias, float* x1, const float* gamma,
+                                            const float* beta, float eps, void* y, int y_dtype, float* mean, float* rstd, int B,
+                                            int S, int n_slots, int C, const int32_t* out_map, int n_out, const int32_t* out_pads,
+                                            int n_out_pads, void* stream) {
     PSWIN_CHECK_ARG(win && resid && x1 && gamma && beta && y && mean && rstd && B > 0 && S > 0 && n_slots > 0);
     PSWIN_CHECK_ARG(valid_dtype(win_dtype) && valid_dtype(y_dtype) && (inv || n_slots == S));
     PSWIN_CHECK_ARG(C >= 8 && C % 8 == 0 && C <= 1024 && aligned16(win) && aligned16(resid) && aligned16(x1) && aligned16(y));
     PSWIN_CHECK_ARG(aligned16(gamma) && aligned16(beta) && aligned16(bias));
+    PSWIN_CHECK_ARG(out_map ? (n_out >= S && n_out_pads == n_out - S && (out_pads || n_out_pads == 0)) : (n_out == S && n_out_pads == 0));
+    const OutMap om = {out_map, out_pads, n_out, n_out_pads, B};
     const long long rows = (long long)B * S;
+    const long long groups = rows + (out_map ? (long long)B * n_out_pads : 0);     // row groups: tokens, then the zero slots
     const int L = pick_lanes(C);
     hipStream_t st = (hipStream_t)stream;
     return dispatch2(win_dtype, y_dtype, [&](auto wd, auto yd) {
@@ -625,8 +695,8 @@ extern "C" int pswin_scatter_add_ln_fwd(const void* win, int win_dtype, const in
     case LL: {                                                                                                             \
         const int rpb = THREADS / LL;                                                                                      \
         hipLaunchKernelGGL((ln_add_fwd_kernel<decltype(wd)::value, decltype(yd)::value, LL, 4>),                            \
-                           dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(THREADS), 0, st, win, inv, resid, scale, bias, x1, \
-                           gamma, beta, eps, y, mean, rstd, rows, S, n_slots, C);                                          \
+                           dim3((unsigned)((groups + rpb - 1) / rpb)), dim3(THREADS), 0, st, win, inv, resid, scale, bias, x1, \
+                           gamma, beta, eps, y, mean, rstd, rows, S, n_slots, C, om);                                      \
         break;                                                                                                             \
     }
         switch (L) {
@@ -639,10 +709,19 @@ extern "C" int pswin_scatter_add_ln_fwd(const void* win, int win_dtype, const in
     });
 }
 
-extern "C" int pswin_ln_gather_bwd(const void* dy, int dy_dtype, const int32_t* inv, const void* x, int x_dtype,
-                                   const float* mean, const float* rstd, const float* gamma, const float* dres,
-                                   const float* res_scale, float* dres_sum, void* dx, float* dgamma, float* dbeta,
-                                   float* workspace, int B, int S, int n_out, int C, void* stream) {
+extern "C" int pswin_scatter_add_ln_fwd(const void* win, int win_dtype, const int32_t* inv, const float* resid,
+                                        const float* scale, const float* bias, float* x1, const float* gamma,
+                                        const float* beta, float eps, void* y, int y_dtype, float* mean, float* rstd, int B,
+                                        int S, int n_slots, int C, void* stream) {
+    return pswin_scatter_add_ln_fwd_map(win, win_dtype, inv, resid, scale, bias, x1, gamma, beta, eps, y, y_dtype, mean, rstd, B, S, n_slots, C,
+                                        nullptr, S, nullptr, 0, stream);
+}
+
+extern "C" int pswin_ln_gather_bwd_ex(const void* dy, int dy_dtype, const int32_t* inv, const void* x, int x_dtype,
+                                      const float* mean, const float* rstd, const float* gamma, const float* dres,
+                                      const float* res_scale, float* dres_sum, void* dx, float* dgamma, float* dbeta,
+                                      float* workspace, int B, int S, int n_out, int C, void* ex, const int32_t* ex_map, int ex_rows,
+                                      const float* ex_scale, const int32_t* ex_pads, int n_ex_pads, void* stream) {
     PSWIN_CHECK_ARG(dy && x && mean && rstd && gamma && dx && workspace && B > 0 && S > 0 && n_out > 0);
     PSWIN_CHECK_ARG((dgamma && dbeta) || (!dgamma && !dbeta));
     PSWIN_CHECK_ARG(valid_dtype(x_dtype) && valid_dtype(dy_dtype));
@@ -650,6 +729,11 @@ extern "C" int pswin_ln_gather_bwd(const void* dy, int dy_dtype, const int32_t* 
     PSWIN_CHECK_ARG(inv || n_out == S);
     PSWIN_CHECK_ARG(!dres || (x_dtype == PSWIN_F32 && aligned16(dres)));
     PSWIN_CHECK_ARG(!dres_sum || dres);
+    if (ex) {
+        PSWIN_CHECK_ARG(x_dtype == PSWIN_F32 && aligned16(ex) && !wide_row(C) && (long long)B * ex_rows * C < 0x7fffffffll);
+        PSWIN_CHECK_ARG(ex_map ? (ex_rows >= S && n_ex_pads == ex_rows - S && (ex_pads || n_ex_pads == 0)) : (ex_rows == S && n_ex_pads == 0));
+    }
+    const BwdExtra be = {ex, ex_map, ex_scale, ex_pads, ex_rows, ex ? n_ex_pads : 0, B};
     RowSrc rs = {0, nullptr, S, n_out, 0, 0, 0};
     const long long rows = (long long)B * S;
     const int L = pick_lanes(C);
@@ -658,13 +742,13 @@ extern "C" int pswin_ln_gather_bwd(const void* dy, int dy_dtype, const int32_t* 
     if (dres_sum) {
         rc = dispatch2(dy_dtype, PSWIN_F32, [&](auto dd, auto xd) {
             return launch_bwd<0, decltype(dd)::value, PSWIN_F32, true>(L, dy, inv, x, rs, mean, rstd, gamma, dx, dres, res_scale,
-                                                                       workspace, rows, C, blocks, (hipStream_t)stream);
+                                                                       workspace, rows, C, blocks, (hipStream_t)stream, be);
         });
     } else {
         rc = dispatch2(dy_dtype, x_dtype, [&](auto dd, auto xd) {
             return launch_bwd<0, decltype(dd)::value, decltype(xd)::value, false>(L, dy, inv, x, rs, mean, rstd, gamma, dx, dres,
                                                                                   nullptr, workspace, rows, C, blocks,
-                                                                                  (hipStream_t)stream);
+                                                                                  (hipStream_t)stream, be);
         });
     }
     if (rc) return rc;
@@ -673,6 +757,14 @@ extern "C" int pswin_ln_gather_bwd(const void* dy, int dy_dtype, const int32_t* 
     // the 3-segment row layout and is not written.
     if (dgamma) launch_colsum_seg(workspace, blocks, C, dres_sum ? 3 : 2, dgamma, dbeta, dres_sum, (hipStream_t)stream);
     PSWIN_LAUNCH_RET();
+}
+
+extern "C" int pswin_ln_gather_bwd(const void* dy, int dy_dtype, const int32_t* inv, const void* x, int x_dtype,
+                                   const float* mean, const float* rstd, const float* gamma, const float* dres,
+                                   const float* res_scale, float* dres_sum, void* dx, float* dgamma, float* dbeta,
+                                   float* workspace, int B, int S, int n_out, int C, void* stream) {
+    return pswin_ln_gather_bwd_ex(dy, dy_dtype, inv, x, x_dtype, mean, rstd, gamma, dres, res_scale, dres_sum, dx, dgamma, dbeta, workspace, B, S,
+                                  n_out, C, nullptr, nullptr, S, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int pswin_ln_patch_merge_fwd(const void* x, int x_dtype, const float* gamma, const float* beta, float eps,

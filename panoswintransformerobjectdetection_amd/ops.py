@@ -261,6 +261,15 @@ def window_maps(pano, H, W, shift, device):
     return _CACHE[key]
 
 
+def window_pads(pano, H, W, shift, device):
+    """int32 [nW*49 - H*W]: the window slots no token maps to (the zero rows of pad_x, HOT:486-491), ascending"""
+    key = ("pads", bool(pano), H, W, shift, _dev_key(device))
+    if key not in _CACHE:
+        wmap, _, _ = window_maps(pano, H, W, shift, device)
+        _CACHE[key] = torch.nonzero(wmap < 0).flatten().to(torch.int32).contiguous()
+    return _CACHE[key]
+
+
 def identity_map(S, device):
     """int32 arange(S): the row movers with this map are plain (scaled, residual-added, dtype-converting) row copies."""
     key = ("ident", S, _dev_key(device))
@@ -487,33 +496,44 @@ def layer_norm_gather(x, gamma, beta, eps, wmap=None, inv=None, out_dtype=None, 
     return _LayerNormGather.apply(x, gamma, beta, eps, wmap, inv, out_dtype or x.dtype, passthrough, res_bias, res_scale)
 
 
+# the window gather (or bf16 cast) of window_scatter_add's backward from inside the LayerNorm backward kernel (pswin_ln_gather_bwd_ex) and
+# the next block's norm1 + partition from inside the residual add (pswin_scatter_add_ln_fwd_map); PSWIN_LN_FUSED_MOVES=0: separate kernels (A/B)
+LN_FUSED_MOVES = os.environ.get("PSWIN_LN_FUSED_MOVES", "1") != "0"
+
+
 class _ScatterAddLayerNorm(torch.autograd.Function):
-    """window_scatter_add + token-order LayerNorm in one forward pass (pswin_scatter_add_ln_fwd); the backward pass is the
-    LayerNorm backward kernel (with the shortcut gradient folded in, as layer_norm_gather(passthrough=True)) followed by
-    the window gather of window_scatter_add's backward."""
+    """window_scatter_add + LayerNorm in one forward pass (pswin_scatter_add_ln_fwd[_map]); the backward pass is the LayerNorm backward
+    kernel (with the shortcut gradient folded in, as layer_norm_gather(passthrough=True)) which also writes the window gather of
+    window_scatter_add's backward (pswin_ln_gather_bwd_ex) -- or, with PSWIN_LN_FUSED_MOVES=0 / fp32 windows, followed by that gather."""
 
     @staticmethod
-    def forward(ctx, win, resid, wmap, inv, scale, bias, gamma, beta, eps, out_dtype, res_bias, res_scale):
+    def forward(ctx, win, resid, wmap, inv, scale, bias, gamma, beta, eps, out_dtype, res_bias, res_scale, in_pads, out_inv, out_n, out_pads):
         B, S, C = resid.shape
         if resid.dtype != torch.float32:
             raise PswinError("scatter_add_layer_norm needs an fp32 residual stream")
         win, resid = win.contiguous(), resid.contiguous()
         x1 = torch.empty_like(resid)
-        y = torch.empty(B, S, C, dtype=out_dtype, device=resid.device)
+        n_y = S if out_inv is None else int(out_n)
+        y = torch.empty(B, n_y, C, dtype=out_dtype, device=resid.device)
         mean = torch.empty(B, S, dtype=torch.float32, device=resid.device)
         rstd = torch.empty_like(mean)
         b = None if bias is None else bias.detach().float().contiguous()
-        call("pswin_scatter_add_ln_fwd", win, ptr(win), dtype_code(win), ptr(inv), ptr(resid), ptr(scale), ptr(b), ptr(x1),
-             ptr(gamma), ptr(beta), float(eps), ptr(y), dtype_code(y), ptr(mean), ptr(rstd), B, S, win.shape[1], C,
-             algo_bytes=B * S * C * (win.element_size() + 8 + y.element_size()))
-        ctx.save_for_backward(x1, gamma, mean, rstd, wmap, scale, res_scale)
-        ctx.win_dtype, ctx.want_res_sum = win.dtype, res_bias is not None
+        abytes = B * C * (win.shape[1] * win.element_size() + 8 * S + n_y * y.element_size())
+        if out_inv is None:
+            call("pswin_scatter_add_ln_fwd", win, ptr(win), dtype_code(win), ptr(inv), ptr(resid), ptr(scale), ptr(b), ptr(x1),
+                 ptr(gamma), ptr(beta), float(eps), ptr(y), dtype_code(y), ptr(mean), ptr(rstd), B, S, win.shape[1], C, algo_bytes=abytes)
+        else:
+            call("pswin_scatter_add_ln_fwd_map", win, ptr(win), dtype_code(win), ptr(inv), ptr(resid), ptr(scale), ptr(b), ptr(x1),
+                 ptr(gamma), ptr(beta), float(eps), ptr(y), dtype_code(y), ptr(mean), ptr(rstd), B, S, win.shape[1], C, ptr(out_inv), n_y,
+                 ptr(out_pads), n_y - S, algo_bytes=abytes, timed_as="pswin_scatter_add_ln_fwd")
+        ctx.save_for_backward(x1, gamma, mean, rstd, wmap, scale, res_scale, inv, in_pads, out_inv)
+        ctx.win_dtype, ctx.want_res_sum, ctx.n_in, ctx.n_y = win.dtype, res_bias is not None, win.shape[1], n_y
         ctx.owners = (gamma, beta, res_bias)
         return y, x1
 
     @staticmethod
     def backward(ctx, dy, dres):
-        x1, gamma, mean, rstd, wmap, scale, res_scale = ctx.saved_tensors
+        x1, gamma, mean, rstd, wmap, scale, res_scale, inv, in_pads, out_inv = ctx.saved_tensors
         B, S, C = x1.shape
         if dy is None:
             raise PswinError("scatter_add_layer_norm: the normalised output must be used")
@@ -525,24 +545,41 @@ class _ScatterAddLayerNorm(torch.autograd.Function):
         lib = _lib.load()
         ws = torch.empty(lib.pswin_ln_workspace(B * S, C), dtype=torch.float32, device=x1.device)
         nseg = 3 if ctx.want_res_sum else 2
-        call("pswin_ln_gather_bwd", x1, ptr(dy), dtype_code(dy), None, ptr(x1), dtype_code(x1), ptr(mean), ptr(rstd),
-             ptr(gamma), ptr(dres), ptr(res_scale), ptr(dres) if ctx.want_res_sum else None, ptr(dx1), None, None, ptr(ws),
-             B, S, S, C, algo_bytes=B * S * C * (dy.element_size() + (2 if dres is None else 3) * 4))
+        n_pads = ctx.n_in - S
+        fused = (LN_FUSED_MOVES and ctx.win_dtype == torch.bfloat16 and C <= 1024 and (inv is not None or n_pads == 0)
+                 and (n_pads == 0 or in_pads is not None))
+        abytes = B * S * C * (dy.element_size() + (2 if dres is None else 3) * 4)
+        if fused:                                            # dwin = scale_b * dx1 through the window map, from the same kernel
+            dwin = torch.empty(B, ctx.n_in, C, dtype=torch.bfloat16, device=x1.device)
+            call("pswin_ln_gather_bwd_ex", x1, ptr(dy), dtype_code(dy), ptr(out_inv), ptr(x1), dtype_code(x1), ptr(mean), ptr(rstd),
+                 ptr(gamma), ptr(dres), ptr(res_scale), ptr(dres) if ctx.want_res_sum else None, ptr(dx1), None, None, ptr(ws),
+                 B, S, ctx.n_y, C, ptr(dwin), ptr(inv), ctx.n_in, ptr(scale), ptr(in_pads), n_pads,
+                 algo_bytes=abytes + B * ctx.n_in * C * 2, timed_as="pswin_ln_gather_bwd")
+        else:
+            call("pswin_ln_gather_bwd", x1, ptr(dy), dtype_code(dy), ptr(out_inv), ptr(x1), dtype_code(x1), ptr(mean), ptr(rstd),
+                 ptr(gamma), ptr(dres), ptr(res_scale), ptr(dres) if ctx.want_res_sum else None, ptr(dx1), None, None, ptr(ws),
+                 B, S, ctx.n_y, C, algo_bytes=abytes)
         sums = sum_rows(ws, lib.pswin_ln_partial_rows(B * S, C), nseg * C, owners=ctx.owners)
         dres_sum = sums[2 * C:] if ctx.want_res_sum else None
-        dwin = _gather_raw(dx1, wmap, scale, wmap.numel(), ctx.win_dtype)          # window_scatter_add's backward
-        return dwin, dx1, None, None, None, None, sums[:C], sums[C:2 * C], None, None, dres_sum, None
+        if not fused:
+            dwin = _gather_raw(dx1, wmap, scale, wmap.numel(), ctx.win_dtype)      # window_scatter_add's backward
+        return dwin, dx1, None, None, None, None, sums[:C], sums[C:2 * C], None, None, dres_sum, None, None, None, None, None
 
 
 def scatter_add_layer_norm(win, resid, wmap, inv, scale, bias, gamma, beta, eps, out_dtype=None, res_bias=None,
-                           res_scale=None):
+                           res_scale=None, in_pads=None, out=None):
     """(y, x1) with x1 = resid + scale_b * (window_reverse(win) + bias) and y = LayerNorm(x1): window_scatter_add(...,
     bias_grad_elsewhere=True) followed by layer_norm_gather(x1, passthrough=True, res_bias=..., res_scale=...) as ONE
     forward kernel (the shortcut sum is not re-read by a LayerNorm kernel).  x1 is the tensor to use for the next
     shortcut.  The gradient of `bias` is not returned here (it comes from the LayerNorm that produced `resid` with
-    res_bias=bias); res_bias / res_scale as in layer_norm_gather."""
+    res_bias=bias); res_bias / res_scale as in layer_norm_gather.
+    inv=None: `win` is in token order (wmap: the identity map).  in_pads: window_pads of the map `win` is laid out by (lets the backward
+    kernel write the gathered gradient itself).  out=(out_inv, n_out, out_pads): y is written through the token -> slot map out_inv into
+    [B, n_out, C] with zero rows at out_pads -- the NEXT block's norm1 + shift + pad + window partition (layer_norm_gather(x1, ..., wmap,
+    inv)) fused into this pass."""
+    out_inv, out_n, out_pads = out if out is not None else (None, 0, None)
     return _ScatterAddLayerNorm.apply(win, resid, wmap, inv, scale, bias, gamma, beta, eps, out_dtype or resid.dtype,
-                                      res_bias, res_scale)
+                                      res_bias, res_scale, in_pads, out_inv, out_n, out_pads)
 
 
 class _LayerNormNCHW(torch.autograd.Function):

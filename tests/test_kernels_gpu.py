@@ -496,6 +496,66 @@ def test_scatter_add_layer_norm_equals_the_two_kernel_path(ops, C, wdt, use_scal
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("C", [96, 192, 384, 768])
+@pytest.mark.parametrize("pano,H,W,shift", [(True, 13, 25, 3), (False, 14, 21, 0), (True, 16, 32, 0)])
+@pytest.mark.parametrize("use_scale", [False, True])
+def test_fused_moves_of_the_layer_norm_kernels_equal_the_separate_row_movers(ops, C, pano, H, W, shift, use_scale):
+    """Round 4: (1) scatter_add_layer_norm(in_pads=...): the backward kernel also writes the window gather of window_scatter_add's backward
+    (pswin_ln_gather_bwd_ex) -- (2) scatter_add_layer_norm(out=...): the residual add that ends a block also runs the NEXT block's norm1
+    + shift + pad + partition (pswin_scatter_add_ln_fwd_map), and its backward kernel writes the bf16 branch gradient.  Both against
+    the chain of separate kernels (window_scatter_add, layer_norm_gather, window_gather): every output and every gradient bit for bit,
+    zero rows in the padding slots included (planar 14 x 21 has none)."""
+    B = 2
+    wmap, inv, nW = ops.window_maps(pano, H, W, shift, DEV)
+    pads = ops.window_pads(pano, H, W, shift, DEV)
+    assert pads.numel() == nW * 49 - H * W and bool((wmap[pads.long()] < 0).all())
+    S = H * W
+    ident = ops.identity_map(S, DEV)
+    gamma, beta = det_uniform((C,), "fm:g", 0.5, 1.0), det_uniform((C,), "fm:b", 0.5)
+    pbias, fbias = det_uniform((C,), "fm:pb", 0.5), det_uniform((C,), "fm:fb", 0.5)
+    s1 = torch.tensor([0.0, 1.25], device=DEV) if use_scale else None
+    s2 = torch.tensor([1.25, 0.5], device=DEV) if use_scale else None
+    x = det_uniform((B, S, C), "fm:x", 2.0)
+    # (1) attention half: window-order input, token-order normalised output
+    win = det_uniform((B, nW * 49, C), "fm:w", 2.0).to(torch.bfloat16)
+    gy, gx = det_uniform((B, S, C), "fm:gy").to(DEV), det_uniform((B, S, C), "fm:gx").to(DEV)
+    res = []
+    for mode in ("chain", "fused"):
+        wd, xd = win.to(DEV).requires_grad_(True), x.to(DEV).requires_grad_(True)
+        gd, bd, pb, fb = [t.to(DEV).requires_grad_(True) for t in (gamma, beta, pbias, fbias)]
+        prev = ops.LN_FUSED_MOVES
+        ops.LN_FUSED_MOVES = mode == "fused"
+        try:
+            y, x1 = ops.scatter_add_layer_norm(wd, xd, wmap, inv, s1, pb, gd, bd, 1e-5, torch.bfloat16, res_bias=fb, res_scale=s2, in_pads=pads)
+            ((y.float() * gy).sum() + (x1 * gx).sum()).backward()
+        finally:
+            ops.LN_FUSED_MOVES = prev
+        res.append((y.detach(), x1.detach(), wd.grad, xd.grad, gd.grad, bd.grad, fb.grad))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    assert bool((res[1][2][:, pads.long()] == 0).all())                # the gathered gradient has zero rows in the padding slots
+    # (2) the join: token-order input (the Mlp output), window-order normalised output through the NEXT block's map
+    ymlp = det_uniform((B, S, C), "fm:m", 2.0).to(torch.bfloat16)
+    gw = det_uniform((B, nW * 49, C), "fm:gw").to(DEV)
+    res = []
+    for mode in ("chain", "fused"):
+        md, xd = ymlp.to(DEV).requires_grad_(True), x.to(DEV).requires_grad_(True)
+        gd, bd, fb, pb = [t.to(DEV).requires_grad_(True) for t in (gamma, beta, fbias, pbias)]
+        if mode == "fused":
+            wn, x1 = ops.scatter_add_layer_norm(md, xd, ident, None, s2, fb, gd, bd, 1e-5, torch.bfloat16, res_bias=pb, res_scale=s1,
+                                                out=(inv, nW * 49, pads))
+        else:
+            x1 = ops.window_scatter_add(md, xd, ident, ident, s2, fb, True)
+            wn, x1 = ops.layer_norm_gather(x1, gd, bd, 1e-5, wmap, inv, torch.bfloat16, passthrough=True, res_bias=pb, res_scale=s1)
+        assert wn.shape == (B, nW * 49, C)
+        ((wn.float() * gw).sum() + (x1 * gx).sum()).backward()
+        res.append((wn.detach(), x1.detach(), md.grad, xd.grad, gd.grad, bd.grad, pb.grad))
+        assert fb.grad is None
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    assert bool((res[1][0][:, pads.long()] == 0).all())
+
+
 @pytest.mark.parametrize("H,W,C", [(8, 16, 96), (16, 32, 192), (4, 8, 768), (16, 32, 96)])
 @pytest.mark.parametrize("passthrough", [False, True])
 def test_layer_norm_nchw(ops, H, W, C, passthrough):
