@@ -146,6 +146,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--bucket-mb", type=float, default=32.0)
     ap.add_argument("--eager", action="store_true", help="do not capture the step into a HIP graph")
+    ap.add_argument("--no-capture", action="store_true",
+                    help="the benched step -- flat gradient buffer, deferred reductions, grouped weight gradients, FlatAdamW -- launched from Python "
+                         "instead of replayed from hipGraphs (rocprofv3 --pmc passes: counter collection on a replayed graph does not finish)")
     ap.add_argument("--model", default="T", choices=["T", "S"], help="PanoSwin-T (depths 2-2-6-2, the headline) or -S (2-2-18-2)")
     ap.add_argument("--height", type=int, default=512, help="panorama height; width = 2 * height (headline: 512)")
     ap.add_argument("--graph-heads", type=int, default=1, help="--config maskrcnn: capture the head stand-ins into a hipGraph too (1) or run them eagerly (0)")
@@ -264,9 +267,15 @@ def main():
         reducer.pack_grads(early_params)
         return carry["g_xb"]
 
-    split = (world > 1 or args.split_backward) and not args.eager
+    split = (world > 1 or args.split_backward) and not args.eager and not args.no_capture
     if args.eager:
         step = eager_step
+    elif args.no_capture:
+        def step():
+            loss = fwd_bwd()
+            reducer.finish()
+            opt.step()
+            return loss
     elif split:
         from panoswintransformerobjectdetection_amd.graph import GraphedCallable, GraphedSequence
         seq = GraphedSequence([phase1, phase2], warmup=2, stream=cap_stream)
@@ -436,7 +445,7 @@ def main():
                                     f"heads 3-6-12-24, ape, pano mode) fwd+bwd+AdamW on 3x{args.height}x{2 * args.height} "
                                     "panoramas" + (", BASELINE.json configs[1]" if (args.model, args.height) == ("T", 512) else "")),
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world, "parallelism": f"dp{world}",
-                       "grad_bucket_mb": args.bucket_mb, "hip_graph": not args.eager, "overlap_allreduce": bool(split),
+                       "grad_bucket_mb": args.bucket_mb, "hip_graph": not args.eager and not args.no_capture, "overlap_allreduce": bool(split),
                        "optimizer": ("AdamW lr 1e-4 wd 0.05, one launch over the flat parameter buffer"
                                      + (", single group (A/B)" if args.single_group or args.eager or args.torch_adamw else
                                         ", parameter groups of the reference's paramwise_cfg (decay_mult 0 for 'norm' parameters)")),

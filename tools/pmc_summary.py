@@ -28,8 +28,14 @@ KERNELS = {"win_fused_fwd_kernel": "pswin_win_attn_fused_fwd", "attn_fwd_kernel"
            "mlp0_bwd_kernel": "pswin_mlp0_bwd", "skinny_gemm_kernel": "pswin_gemm_skinny"}
 
 
+# entry points whose ONE call launches one kernel per template instantiation seen (round 4: the grouped weight-gradient call = one
+# gemm_tn_ring_kernel launch per tile geometry): their "launch" below is the call, i.e. kernel launches / distinct instantiations
+PER_CALL = {"pswin_gemm_tn_ring"}
+
+
 def collect(path, counter):
     acc = defaultdict(lambda: [0.0, 0])
+    variants = defaultdict(set)
     for r in csv.DictReader(open(path)):
         if r["Counter_Name"] != counter:
             continue
@@ -38,6 +44,10 @@ def collect(path, counter):
             name = KERNELS[max(hits, key=len)]
             acc[name][0] += float(r["Counter_Value"]) * 1024.0
             acc[name][1] += 1
+            variants[name].add(r["Kernel_Name"])
+    for name in PER_CALL:
+        if name in acc and len(variants[name]) > 1:
+            acc[name][1] = max(1, acc[name][1] // len(variants[name]))
     return acc
 
 

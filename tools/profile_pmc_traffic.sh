@@ -4,7 +4,7 @@ set -u
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/prof
 mkdir -p $O; rm -rf $O/fetch $O/write
-PMCBENCH="python3 bench.py --eager --steps 2 --warmup 1 --no-cpu-baseline --kernel-steps 0 --sustain-steps 0"
+PMCBENCH="python3 bench.py --no-capture --steps 2 --warmup 1 --no-cpu-baseline --kernel-steps 0 --sustain-steps 0"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $PMCBENCH > /dev/null 2> $O/fetch.err
 echo "fetch pass done"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- $PMCBENCH > /dev/null 2> $O/write.err

@@ -12,8 +12,8 @@ python3 tools/prof_summary.py $(ls $O/kt/*/*kernel_stats.csv | head -1) 25 60 > 
 python3 tools/trace_steps.py $(ls $O/kt/*/*kernel_trace.csv | head -1) 10 60 > $O/step_breakdown.txt 2>&1
 cp $(ls $O/kt/*/*kernel_stats.csv | head -1) $O/kernel_stats.csv
 echo "kernel trace done"
-# counter passes on eager steps (a replayed hipGraph under counter collection does not finish in reasonable time)
-PMCBENCH="python3 bench.py --eager --steps 2 --warmup 1 --no-cpu-baseline --kernel-steps 0 --sustain-steps 0"
+# counter passes on the benched step launched from Python (--no-capture: a replayed hipGraph under counter collection does not finish in reasonable time)
+PMCBENCH="python3 bench.py --no-capture --steps 2 --warmup 1 --no-cpu-baseline --kernel-steps 0 --sustain-steps 0"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $PMCBENCH > /dev/null 2> $O/fetch.err
 echo "fetch pass done"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- $PMCBENCH > /dev/null 2> $O/write.err
