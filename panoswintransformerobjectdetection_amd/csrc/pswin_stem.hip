@@ -21,8 +21,6 @@
 // pixel count); y2, dy2 [B][H][W][64] bf16; tokens [B*H/4*W/4][96] bf16.
 // Weights are repacked by the caller (tiny): w1p [32][12 taps][4] (taps 9..11 and channel 3 zero), w2p [9][64 out][32 in],
 // w2t [9][32 in][64 out], w3p [16][96 out][64 in], w3t [16][64 in][96 out], all bf16.
-#include <cstdlib>
-
 #include "pswin_common.hpp"
 
 using namespace pswin;
@@ -724,16 +722,6 @@ int pswin_stem_conv2_fwd(const void* x4, const void* w1p, const float* scale1, c
     PSWIN_CHECK_ARG(x4 && w1p && scale1 && shift1 && w2p && y2 && B > 0 && H > 0 && W > 0);
     PSWIN_CHECK_ARG((long long)H * W * 128 < 0xFFFFFF00ll);
     PSWIN_CHECK_ARG(!sums2 || workspace);
-    static const int th = [] { const char* e = getenv("PSWIN_STEM_CONV2_FWD_TH"); return e ? atoi(e) : 16; }();     // (A/B switch of round 4)
-    if (th == 8) {
-        using namespace t8;
-        const int nty = (H + TH - 1) / TH, ntx = (W + TW - 1) / TW, ntiles = B * nty * ntx;
-        const int grid = grid_for(ntiles, 2);
-        hipLaunchKernelGGL(stem_conv2_fwd_kernel, dim3(grid), dim3(WG), 0, (hipStream_t)stream, reinterpret_cast<const u64*>(x4),
-                           w1p, scale1, shift1, w2p, H, W, nty, ntx, ntiles, y2, sums2 ? workspace : nullptr);
-        if (sums2) launch_colsum(workspace, grid * NW, PART2, sums2, (hipStream_t)stream);
-        PSWIN_LAUNCH_RET();
-    }
     using namespace t16;
     const int nty = (H + TH - 1) / TH, ntx = (W + TW - 1) / TW, ntiles = B * nty * ntx;
     const int grid = grid_for(ntiles, 1);
