@@ -20,6 +20,8 @@
 //     packed [49][32] blocks and the log-sum-exp rows for pswin_attn_bwd_ex.
 // Rounding points are those of the unfused bf16 path: q, k, v and the attention output are rounded to bf16 before they are used as
 // operands / stored; scores, softmax and all accumulation are f32.
+#include <cstdlib>
+
 #include "pswin_attn_frag.hpp"
 
 using namespace pswin;
@@ -42,6 +44,7 @@ struct QkvAttnArgs {
     float* lse;             // SAVE: [n][heads][64] f32
     int n_dist, n_mask, nb, reps, heads;
     float scale;
+    int group;              // bias windows a workgroup has in LDS at a time (round 4): 1, or 8 / reps' for small batches
 };
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -80,6 +83,11 @@ struct QGeom {
     static constexpr int TAB_BYTES = 2 * TABP * 4;
     static constexpr int BIAS_BYTES = TOK * PADT * 4;              // one head: [query][64 keys] f32
     static constexpr int LDS = W_BYTES + BQ_BYTES + TAB_BYTES + 2 * BIAS_BYTES + 15 * 256;      // + 15 rows: padded query rows read past 49
+    // Round 4, small batches: with `reps` < 8 images per bias window only `reps` of the 8 waves had an item.  A workgroup now keeps
+    // GROUP windows' bias tables in LDS at once (double buffered like the single one) and its waves are (window of the group, image)
+    // pairs: batch 2 fills all 8 waves at C = 192 (4 windows x 2 images) and 4 at C = 384 (the 72 KB of weight rows leave room for 2).
+    static constexpr int GROUP_MAX = (160 * 1024 - W_BYTES - BQ_BYTES - TAB_BYTES - 15 * 256) / (2 * BIAS_BYTES) >= 4 ? 4 : 2;
+    static constexpr int lds_bytes(int group) { return W_BYTES + BQ_BYTES + TAB_BYTES + 2 * group * BIAS_BYTES + 15 * 256; }
     static_assert(KS % 2 == 0, "the channel loop is unrolled by two");
 };
 
@@ -95,7 +103,7 @@ __global__ __launch_bounds__(QTHREADS, 2) void qkv_attn_fwd_kernel(QkvAttnArgs a
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
 #ifdef PSWIN_QA_PROBE
-    unsigned long long* qa_st = reinterpret_cast<unsigned long long*>(smem + G::LDS) + wave * QA_SLOTS;
+    unsigned long long* qa_st = reinterpret_cast<unsigned long long*>(smem + G::lds_bytes(a.group)) + wave * QA_SLOTS;
     if (lane < QA_SLOTS) qa_st[lane] = 0;
     QA_STAMP(0);
 #endif
@@ -370,8 +378,13 @@ __global__ __launch_bounds__(QTHREADS, 2) void qkv_attn_fwd_kernel(QkvAttnArgs a
     };
 
     // prologue, continued: the first window's quads and the first item's first steps join the requests above, then the LDS image
+    // Window walk: the workgroup's windows are wb0, wb0 + wstride, ...; it takes GRP of them per round.  GRP == 1 (batches >= 8): the
+    // waves are the images of the one window (rep = wave, wave + 8, ...).  GRP > 1: wave = (window gw of the round, image gr).
+    const int GRP = a.group, RPW = QWAVES / GRP;                     // images per window a round can take
+    const int gw = wave / RPW, gr = wave - gw * RPW;
     if (wb0 < a.nb) fetch_bias(wb0);
-    rsrc_t xs = make_xs(wb0, wave, wb0 < a.nb && wave < a.reps);
+    const int first_w = wb0 + gw * wstride;
+    rsrc_t xs = make_xs(first_w, gr, first_w < a.nb && gr < a.reps);
 #pragma unroll
     for (int s = 0; s < (PAIRS ? XD - 2 : XD - 1); ++s) load_x(xs, s, xr[s]);
 #pragma unroll
@@ -389,21 +402,33 @@ __global__ __launch_bounds__(QTHREADS, 2) void qkv_attn_fwd_kernel(QkvAttnArgs a
     __syncthreads();                                  // weights and tables staged
     QA_STAMP(2);
     if (wb0 < a.nb) finish_bias(bias);
+    for (int g = 1; g < GRP; ++g) {                   // the other windows of the first round (small batches only)
+        const int wg_ = wb0 + g * wstride;
+        if (wg_ < a.nb) {
+            fetch_bias(wg_);
+            finish_bias(bias + g * G::BIAS_BYTES);
+        }
+    }
     __syncthreads();
     QA_STAMP(3);
     int par = 0;
     [[maybe_unused]] int qa_it = 0;
-    for (int wb = wb0; wb < a.nb; wb += wstride, par ^= 1) {
-        const char* bcur = bias + par * G::BIAS_BYTES;
-        const int wn = wb + wstride;
-        for (int rep = wave; rep < a.reps; rep += QWAVES) {
-            int nrep = rep + QWAVES, nwb = wb;
+    const int rstride = GRP * wstride;                // windows per round
+    for (int wb = wb0; wb < a.nb; wb += rstride, par ^= 1) {
+        const char* bround = bias + par * GRP * G::BIAS_BYTES;
+        const int wn = wb + rstride;
+        // ONE call site for both modes (two inlined copies of the item spilled): GRP == 1 gives gw = 0, gr = wave, RPW = 8 -- the image
+        // loop of rounds 2-3; GRP > 1 gives at most one trip
+        const int wmine = wb + gw * wstride;
+        const char* bcur = bround + gw * G::BIAS_BYTES;
+        for (int rep = gr; rep < a.reps && wmine < a.nb; rep += RPW) {
+            int nrep = rep + RPW, nwb = wmine;
             if (nrep >= a.reps) {
-                nrep = wave;
-                nwb = wn;
+                nrep = gr;
+                nwb = wmine + rstride;
             }
             const rsrc_t xn = make_xs(nwb, nrep, nwb < a.nb);
-            const size_t win = (size_t)rep * a.nb + wb;
+            const size_t win = (size_t)rep * a.nb + wmine;
             static_assert(KS % XD == 0, "every item starts at ring slot 0");
             item.template operator()<0>(win, xs, xn, bcur, 4 + 6 * qa_it);
             xs = xn;
@@ -411,9 +436,12 @@ __global__ __launch_bounds__(QTHREADS, 2) void qkv_attn_fwd_kernel(QkvAttnArgs a
         // (requesting the next window's quads before the score chain and finishing them here was tried: the sixteen registers they
         // hold across the chain spilled the finish's table indices, whose scratch reloads then waited out the item's stores --
         // 1.8 -> 4.5 us for this phase in the probe)
-        if (wn < a.nb) {
-            fetch_bias(wn);
-            finish_bias(bias + (par ^ 1) * G::BIAS_BYTES);
+        for (int g = 0; g < GRP; ++g) {
+            const int wg_ = wn + g * wstride;
+            if (wg_ < a.nb) {
+                fetch_bias(wg_);
+                finish_bias(bias + ((par ^ 1) * GRP + g) * G::BIAS_BYTES);
+            }
         }
         QA_STAMP(4 + 6 * qa_it + 4);
         __syncthreads();
@@ -428,15 +456,29 @@ __global__ __launch_bounds__(QTHREADS, 2) void qkv_attn_fwd_kernel(QkvAttnArgs a
 }
 
 template <int C, bool SAVE>
-int launch_qkv_attn(const QkvAttnArgs& a, hipStream_t st) {
+int launch_qkv_attn(QkvAttnArgs a, hipStream_t st) {
+    using G = QGeom<C>;
     static std::atomic<unsigned long long> configured{0};
+    // windows per round: as many as it takes to give every wave an image (8 / reps, reps rounded up to a power of two), capped by LDS
+    int group = 1;
+    if (a.reps < QWAVES) {
+        int rp = 1;
+        while (rp < a.reps) rp *= 2;
+        group = QWAVES / rp;
+        if (group > G::GROUP_MAX) group = G::GROUP_MAX;
+        static const int cap = [] { const char* e = getenv("PSWIN_QKV_ATTN_GROUP_MAX"); return e ? atoi(e) : 8; }();     // (A/B: 1 = the round-3 wave assignment)
+        if (group > cap) group = cap < 1 ? 1 : cap;
+    }
+    a.group = group;
 #ifdef PSWIN_QA_PROBE
-    constexpr int lds_bytes = QGeom<C>::LDS + QWAVES * QA_SLOTS * 8;
+    constexpr int probe_bytes = QWAVES * QA_SLOTS * 8;
 #else
-    constexpr int lds_bytes = QGeom<C>::LDS;
+    constexpr int probe_bytes = 0;
 #endif
-    if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&qkv_attn_fwd_kernel<C, SAVE>), lds_bytes, configured)) return rc;
-    long long items = (long long)a.nb * a.heads;
+    static_assert(G::lds_bytes(G::GROUP_MAX) + probe_bytes <= 160 * 1024, "LDS");
+    if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&qkv_attn_fwd_kernel<C, SAVE>), G::lds_bytes(G::GROUP_MAX) + probe_bytes, configured)) return rc;
+    const int lds_bytes = G::lds_bytes(group) + probe_bytes;
+    long long items = ((long long)a.nb + group - 1) / group * a.heads;           // (round of windows, head) pairs
     int grid = items < 256 ? (int)items : 256 / a.heads * a.heads;        // a multiple of `heads`: workgroup b owns head b % heads
     hipLaunchKernelGGL((qkv_attn_fwd_kernel<C, SAVE>), dim3(grid), dim3(QTHREADS), lds_bytes, st, a);
     PSWIN_LAUNCH_RET();

@@ -773,7 +773,11 @@ def test_fused_window_attention_equals_the_three_kernel_chain(ops, B, nW, pano, 
 QKV_FUSED_CASES = [(192, 2, 3, True, 0), (192, 1, 5, False, 0), (192, 3, 4, False, 3), (192, 2, 3, False, 4), (192, 9, 2, True, 0),
                    (192, 8, 50, True, 0), (384, 2, 3, True, 0), (384, 2, 3, False, 3), (384, 8, 25, True, 0), (384, 1, 1, True, 0),
                    # more images than waves: two or three items per wave and bias window (the activation ring runs on across them)
-                   (384, 9, 3, False, 4), (384, 17, 2, True, 3), (192, 20, 2, True, 0)]
+                   (384, 9, 3, False, 4), (384, 17, 2, True, 3), (192, 20, 2, True, 0),
+                   # round 4, small batches: several bias windows per workgroup round (4 at C = 192, 2 at C = 384), full and ragged rounds,
+                   # more rounds than one, 1 / 2 / 4 images per window
+                   (192, 2, 50, True, 0), (384, 2, 50, True, 0), (192, 4, 7, False, 3), (384, 4, 9, True, 0), (192, 1, 1, True, 0),
+                   (192, 1, 190, True, 0), (384, 1, 13, False, 3)]
 
 
 @pytest.mark.parametrize("C,B,nW,pano,mask_kind", QKV_FUSED_CASES)

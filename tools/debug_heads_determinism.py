@@ -8,6 +8,9 @@ from _util import TCFG
 from panoswintransformerobjectdetection_amd.detector import MiniMaskRCNN, synthetic_targets
 
 DEV = "cuda:0"
+import os, time
+if os.environ.get("PSWIN_HEADS_DETERMINISTIC") == "1":          # MIOpen: exclude non-deterministic solvers (miopenConvolutionAttribDeterministic)
+    torch.backends.cudnn.deterministic = True
 torch.manual_seed(0)
 cfg = dict(TCFG, drop_path_rate=0.0, compute_dtype=torch.bfloat16)
 m = MiniMaskRCNN(cfg, num_classes=80).to(DEV).train()
@@ -26,6 +29,7 @@ def rel(a, b):
 
 ref = None
 for run in range(6):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
     feats = [o.detach().clone().requires_grad_(True) for o in outs]
     ls = m.heads_loss(feats, tg, (H, W))
     row = {}
@@ -34,7 +38,8 @@ for run in range(6):
         row[k] = (float(ls[k]), [None if t is None else t.detach().clone() for t in g])
     if ref is None:
         ref = row
-    print("run", run, flush=True)
+    torch.cuda.synchronize()
+    print("run", run, f"{(time.perf_counter() - t0) * 1e3:.1f} ms (eager, incl. the per-loss gradient passes)", flush=True)
     for k, (v, g) in row.items():
         d = [None if (a is None or b is None) else round(rel(a, b), 6) for a, b in zip(g, ref[k][1])]
         print(f"   {k:14s} {v:.9f}  (run 0: {ref[k][0]:.9f})  grad rel vs run 0: {d}", flush=True)
