@@ -284,26 +284,34 @@ constexpr int W3T_LD = 208;                    // 96 bf16 + 16 bytes: 8 rows x 1
 constexpr int W3T_BYTES = C2 * W3T_LD;
 constexpr int PART3 = 2 * C2;
 
+// Round 4: persistent, one workgroup per CU, no barrier inside the tap loop.  The round-1 form gave every 128-token group a workgroup
+// of its own that walked the 16 taps with a weight slice staged per tap (a barrier and a one-step-ahead prefetch per tap): with one
+// workgroup resident per CU each tap cost one HBM round trip (1.8 us; 234 us for a pass whose traffic takes 110).  Now HALF of the taps'
+// weight slices (8 x 13 KB = 104 KB) are resident in LDS at a time, a workgroup streams ALL its token groups past them, then loads the
+// other half and streams again (d tokens re-read: 192 B against 2 KB of y2 per token) -- two barriers per workgroup lifetime; the 8 waves
+// run free, each on its own 16 tokens, with the y2 rows of the next four taps in flight in a register ring that runs on into the wave's
+// next token group.
+constexpr int W3H_TAPS = 8;
+constexpr int W3H_BYTES = W3H_TAPS * W3T_BYTES;            // 106,496
+
+__device__ inline rsrc_t uniform_rsrc(const void* base, long long bytes) {      // a buffer resource the compiler can see is wave-uniform
+    const unsigned long long v = (unsigned long long)base;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    const int n = (int)(bytes > 0xFFFFFFFFll ? 0xFFFFFFFFll : (bytes < 0 ? 0 : bytes));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, __builtin_amdgcn_readfirstlane(n), 0x00020000);
+}
+
 template <bool APPLY>
-__global__ __launch_bounds__(TWG) void stem_conv3_bwd_kernel(const void* __restrict__ dtok, const void* __restrict__ y2,
-                                                            const float* __restrict__ prm, const void* __restrict__ w3t,
-                                                            int H, int W, long long M, long long y2_bytes,
-                                                            void* __restrict__ dy2, float* __restrict__ partial) {
-    __shared__ __attribute__((aligned(16))) char w3s[2][W3T_BYTES];
+__global__ __launch_bounds__(TWG, 2) void stem_conv3_bwd_kernel(const void* __restrict__ dtok, const void* __restrict__ y2,
+                                                               const float* __restrict__ prm, const void* __restrict__ w3t,
+                                                               int H, int W, long long M, long long y2_bytes,
+                                                               void* __restrict__ dy2, float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) char w3h[];          // [8 taps][64 in][208 B]
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int c = lane & 15, g = lane >> 4;
     const int Hh = H / 4, Wh = W / 4;
-    const long long tok_wg = (long long)blockIdx.x * TOK_WG;
-    long long tok = tok_wg + wave * 16 + c;
-    const bool valid = tok < M;
-    if (!valid) tok = M - 1;
-    const long long base_pix = token_pix(tok_wg, Hh, Wh, H, W);
-    const long long rem_bytes = y2_bytes - base_pix * 128;
-    const int nrec = (int)(rem_bytes > 0xFFFFFFFFll ? 0xFFFFFFFFll : rem_bytes);
-    const rsrc_t ys = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(y2)) + base_pix * 128, 0, nrec, 0x00020000);
-    const rsrc_t ds = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(dy2) + base_pix * 128, 0, APPLY ? nrec : 0, 0x00020000);
     const int d0 = row8_d0(g);
-    const unsigned voff = (unsigned)((token_pix(tok, Hh, Wh, H, W) - base_pix) * 128) + 2u * d0;
+    const long long ngroups = (M + TOK_WG - 1) / TOK_WG;
     // per-lane channels: 32 h + d0 + j
     float p0[2][8], p1[2][8], p2[2][8], p3[2][8], p4[2][8];
 #pragma unroll
@@ -313,104 +321,148 @@ __global__ __launch_bounds__(TWG) void stem_conv3_bwd_kernel(const void* __restr
             const int ch = 32 * h + d0 + j;
             p0[h][j] = prm[ch];
             p1[h][j] = prm[C2 + ch];
-            p2[h][j] = prm[2 * C2 + ch];
-            p3[h][j] = prm[3 * C2 + ch];
+            // the statistics pass needs (a, b) of yhat = a y + b only once, at the end: it accumulates sum g y and finishes
+            // sum g yhat = a sum g y + b sum g there (32 registers less in the tap loop, which spilled with them)
+            p2[h][j] = APPLY ? prm[2 * C2 + ch] : 0.f;
+            p3[h][j] = APPLY ? prm[3 * C2 + ch] : 0.f;
             p4[h][j] = APPLY ? prm[4 * C2 + ch] : 0.f;
         }
-    // d tokens as B operands: k = output channel 32 s + 8 g ..
-    bf16x8 bt[3];
-    {
-        const char* src = reinterpret_cast<const char*>(dtok) + tok * (C3 * 2) + 16 * g;
-#pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            u32x4 raw = *reinterpret_cast<const u32x4*>(src + 64 * s);
-            if (!valid) raw = u32x4{0u, 0u, 0u, 0u};
-            bt[s] = __builtin_bit_cast(bf16x8, raw);
-        }
-    }
-    const u32x4* wsrc = reinterpret_cast<const u32x4*>(w3t);
-    const int ch0 = threadIdx.x, ch1 = threadIdx.x + TWG;
-    auto stage_load = [&](int tap, u32x4& r0, u32x4& r1) {
-        r0 = wsrc[tap * 768 + ch0];
-        if (ch1 < 768) r1 = wsrc[tap * 768 + ch1];
-    };
-    auto stage_store = [&](int buf, const u32x4& r0, const u32x4& r1) {
-        *reinterpret_cast<u32x4*>(w3s[buf] + (ch0 / 12) * W3T_LD + (ch0 % 12) * 16) = r0;
-        if (ch1 < 768) *reinterpret_cast<u32x4*>(w3s[buf] + (ch1 / 12) * W3T_LD + (ch1 % 12) * 16) = r1;
-    };
-    u32x4 r0, r1 = {0u, 0u, 0u, 0u};
-    stage_load(0, r0, r1);
-    stage_store(0, r0, r1);
-    u32x4 yb[2], yn[2];
-    yb[0] = __builtin_amdgcn_raw_buffer_load_b128(ys, voff, 0, 0);
-    yb[1] = __builtin_amdgcn_raw_buffer_load_b128(ys, voff + 64u, 0, 0);
     float sg[2][8], sgy[2][8];
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int j = 0; j < 8; ++j) sg[h][j] = sgy[h][j] = 0.f;
-    __syncthreads();
-    for (int tap = 0; tap < 16; ++tap) {
-        const int buf = tap & 1;
-        const int soff = ((tap >> 2) * W + (tap & 3)) * 128;
-        if (tap + 1 < 16) {
-            stage_load(tap + 1, r0, r1);
-            const int nt = tap + 1;
-            const int so = ((nt >> 2) * W + (nt & 3)) * 128;
-            yn[0] = __builtin_amdgcn_raw_buffer_load_b128(ys, voff, so, 0);
-            yn[1] = __builtin_amdgcn_raw_buffer_load_b128(ys, voff + 64u, so, 0);
-        }
-        f32x4 acc[4];
+
+    // one token group of this wave: resources based at the group's first pixel, the lane's token offset, its d-token fragments
+    struct Grp {
+        rsrc_t ys, ds;
+        unsigned voff;
+        bool valid;
+    };
+    auto group_of = [&](long long grp) {
+        Grp r;
+        const long long tok_wg = grp * TOK_WG;
+        long long tok = tok_wg + wave * 16 + c;
+        r.valid = grp < ngroups && tok < M;
+        if (tok >= M) tok = M - 1;
+        const long long base_pix = token_pix(tok_wg < M ? tok_wg : M - 1, Hh, Wh, H, W);
+        const long long rem = grp < ngroups ? y2_bytes - base_pix * 128 : 0;
+        r.ys = uniform_rsrc(reinterpret_cast<const char*>(y2) + base_pix * 128, rem);
+        r.ds = uniform_rsrc(reinterpret_cast<char*>(dy2) + base_pix * 128, APPLY ? rem : 0);
+        r.voff = (unsigned)((token_pix(tok, Hh, Wh, H, W) - base_pix) * 128) + 2u * d0;
+        return r;
+    };
+    const rsrc_t dts = uniform_rsrc(dtok, M * (long long)(C3 * 2));
+    auto load_bt = [&](long long grp, bf16x8 (&bt)[3]) {         // d tokens as B operands: k = output channel 32 s + 8 g ..
+        const long long tok = grp * TOK_WG + wave * 16 + c;
+        const unsigned off = (grp < ngroups && tok < M) ? (unsigned)(tok * (C3 * 2) + 16 * g) : 0xFFFFFF00u;       // past the end: zeros
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < 3; ++s) bt[s] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(dts, off == 0xFFFFFF00u ? off : off + 64u * s, 0, 0));
+    };
+    auto tap_off = [&](int tap) { return ((tap >> 2) * W + (tap & 3)) * 128; };
+
+    for (int half = 0; half < 2; ++half) {
+        // this half's eight weight slices -> LDS (12 requests per thread, all in flight together)
+        __syncthreads();
+        {
+            const u32x4* wsrc = reinterpret_cast<const u32x4*>(w3t) + (size_t)half * W3H_TAPS * 768;
+            constexpr int WIT = W3H_TAPS * 768 / TWG;
+            u32x4 wr[WIT];
 #pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                const bf16x8 a = *reinterpret_cast<const bf16x8*>(w3s[buf] + (16 * mt + c) * W3T_LD + (4 * s + g) * 16);
-                acc[mt] = mfma32(a, bt[s], acc[mt]);
+            for (int it = 0; it < WIT; ++it) wr[it] = wsrc[threadIdx.x + it * TWG];
+#pragma unroll
+            for (int it = 0; it < WIT; ++it) {
+                const int i = threadIdx.x + it * TWG;
+                const int tap = i / 768, ch = i - tap * 768;
+                *reinterpret_cast<u32x4*>(w3h + tap * W3T_BYTES + (ch / 12) * W3T_LD + (ch % 12) * 16) = wr[it];
             }
-        }
-        // acc[mt][e] = d a2[channel 16 mt + 4 g + e][token c] -> 8 consecutive channels 32 h + d0 .. per lane
-        exchange_row8(acc[0], acc[1]);
-        exchange_row8(acc[2], acc[3]);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            float y[8], v[8];
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                y[2 * d] = bf_lo(yb[h][d]);
-                y[2 * d + 1] = bf_hi(yb[h][d]);
-            }
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float da = acc[2 * h + (j >> 2)][j & 3];
-                const bool on = __builtin_fmaf(y[j], p0[h][j], p1[h][j]) > 0.f;
-                const float gg = on ? da : 0.f;
-                if constexpr (APPLY) {
-                    v[j] = __builtin_fmaf(p2[h][j], gg, -__builtin_fmaf(p3[h][j], y[j], p4[h][j]));
-                } else {
-                    const float yh = __builtin_fmaf(y[j], p2[h][j], p3[h][j]);
-                    sg[h][j] += gg;
-                    sgy[h][j] = __builtin_fmaf(gg, yh, sgy[h][j]);
-                }
-            }
-            if constexpr (APPLY) {
-                const u32x4 o = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
-                // The tap offset rides in the VECTOR offset, not in the scalar one.  hipcc's hazard recognizer pads a 128-bit buffer
-                // store against the next VALU write of its data registers only when the store has NO scalar-register offset (the rule
-                // of the older GCN parts); with `soff` in an SGPR it pads nothing, and the next pixel's arithmetic, which reuses the
-                // four data registers one wait state later, overwrote them before the store had read them -- deterministically wrong
-                // dy2 (f32 bit patterns where bf16 pairs belong) once the packing got short enough (one v_cvt_pk_bf16_f32 per pair) to
-                // put the overwrite that close; DESIGN.md section 5, "the stem's non-finite gradients".
-                if (valid) __builtin_amdgcn_raw_buffer_store_b128(o, ds, voff + 64u * h + (unsigned)soff, 0, 0);
-            }
-        }
-        if (tap + 1 < 16) {
-            stage_store(buf ^ 1, r0, r1);
-            yb[0] = yn[0];
-            yb[1] = yn[1];
         }
         __syncthreads();
+        long long grp = blockIdx.x;
+        Grp cur = group_of(grp);
+        bf16x8 bt[3], btn[3];
+        load_bt(grp, bt);
+        u32x4 yq[4][2];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int so = tap_off(W3H_TAPS * half + u);
+            yq[u][0] = __builtin_amdgcn_raw_buffer_load_b128(cur.ys, cur.voff, so, 0);
+            yq[u][1] = __builtin_amdgcn_raw_buffer_load_b128(cur.ys, cur.voff + 64u, so, 0);
+        }
+        for (; grp < ngroups; grp += gridDim.x) {
+            const Grp nxt = group_of(grp + gridDim.x);
+#pragma unroll
+            for (int t8 = 0; t8 < W3H_TAPS; ++t8) {
+                const int tap = W3H_TAPS * half + t8;
+                // (scheduling barriers at the tap boundaries: without them the compiler hoists the weight-fragment reads of all eight
+                // unrolled taps -- 384 registers -- to the top of the loop and spills)
+                __builtin_amdgcn_sched_barrier(0);
+                if (t8 == 4) load_bt(grp + gridDim.x, btn);         // the next group's d tokens travel with its first y2 rows
+                f32x4 acc[4];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) {
+                    acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < 3; ++s) {
+                        const bf16x8 a = *reinterpret_cast<const bf16x8*>(w3h + t8 * W3T_BYTES + (16 * mt + c) * W3T_LD + (4 * s + g) * 16);
+                        acc[mt] = mfma32(a, bt[s], acc[mt]);
+                    }
+                }
+                // acc[mt][e] = d a2[channel 16 mt + 4 g + e][token c] -> 8 consecutive channels 32 h + d0 .. per lane
+                __builtin_amdgcn_sched_barrier(0);
+                exchange_row8(acc[0], acc[1]);
+                exchange_row8(acc[2], acc[3]);
+                const int soff = tap_off(tap);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const u32x4 yb = yq[t8 & 3][h];
+                    float y[8], v[8];
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        y[2 * d] = bf_lo(yb[d]);
+                        y[2 * d + 1] = bf_hi(yb[d]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float da = acc[2 * h + (j >> 2)][j & 3];
+                        const bool on = __builtin_fmaf(y[j], p0[h][j], p1[h][j]) > 0.f;
+                        const float gg = on ? da : 0.f;
+                        if constexpr (APPLY) {
+                            v[j] = __builtin_fmaf(p2[h][j], gg, -__builtin_fmaf(p3[h][j], y[j], p4[h][j]));
+                        } else {
+                            sg[h][j] += gg;
+                            sgy[h][j] = __builtin_fmaf(gg, y[j], sgy[h][j]);
+                            // pin the update to its tap: left alone, the vectorizer pairs the accumulations of the eight unrolled taps and
+                            // sinks them behind the loop body, keeping every tap's 16 accumulator registers alive (120 spilled registers)
+                            asm volatile("" : "+v"(sg[h][j]), "+v"(sgy[h][j]));
+                        }
+                    }
+                    if constexpr (APPLY) {
+                        const u32x4 o = {pack_bf16(v[0], v[1]), pack_bf16(v[2], v[3]), pack_bf16(v[4], v[5]), pack_bf16(v[6], v[7])};
+                        // The tap offset rides in the VECTOR offset, not in the scalar one.  hipcc's hazard recognizer pads a 128-bit buffer
+                        // store against the next VALU write of its data registers only when the store has NO scalar-register offset (the rule
+                        // of the older GCN parts); with `soff` in an SGPR it pads nothing, and the next pixel's arithmetic, which reuses the
+                        // four data registers one wait state later, overwrote them before the store had read them -- deterministically wrong
+                        // dy2 (f32 bit patterns where bf16 pairs belong) once the packing got short enough (one v_cvt_pk_bf16_f32 per pair) to
+                        // put the overwrite that close; DESIGN.md section 5, "the stem's non-finite gradients".
+                        if (cur.valid) __builtin_amdgcn_raw_buffer_store_b128(o, cur.ds, cur.voff + 64u * h + (unsigned)soff, 0, 0);
+                    }
+                }
+                // ring: the slot just consumed takes the y2 rows four taps on -- of this group, or of the wave's next group
+                {
+                    const bool same = t8 + 4 < W3H_TAPS;
+                    const int so = tap_off(W3H_TAPS * half + ((t8 + 4) & (W3H_TAPS - 1)));
+                    const rsrc_t& rs = same ? cur.ys : nxt.ys;
+                    const unsigned vo = same ? cur.voff : nxt.voff;
+                    yq[t8 & 3][0] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0);
+                    yq[t8 & 3][1] = __builtin_amdgcn_raw_buffer_load_b128(rs, vo + 64u, so, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            cur = nxt;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) bt[s] = btn[s];
+        }
     }
     if constexpr (!APPLY) {
         float* out = partial + ((size_t)blockIdx.x * TNW + wave) * PART3;
@@ -418,10 +470,11 @@ __global__ __launch_bounds__(TWG) void stem_conv3_bwd_kernel(const void* __restr
         for (int h = 0; h < 2; ++h)
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
+                const int ch = 32 * h + d0 + j;
                 const float a = row16_sum(sg[h][j]), b = row16_sum(sgy[h][j]);
                 if (c == 0) {
-                    out[32 * h + d0 + j] = a;
-                    out[C2 + 32 * h + d0 + j] = b;
+                    out[ch] = a;
+                    out[C2 + ch] = __builtin_fmaf(prm[2 * C2 + ch], b, prm[3 * C2 + ch] * a);      // sum g yhat = a' sum g y + b' sum g
                 }
             }
     }
@@ -746,9 +799,12 @@ int pswin_stem_conv3_bwd_stats(const void* dtok, const void* y2, const float* pr
                                float* sums, float* workspace, void* stream) {
     PSWIN_CHECK_ARG(dtok && y2 && prm && w3t && sums && workspace && B > 0 && H > 0 && W > 0 && H % 4 == 0 && W % 4 == 0);
     const long long M = (long long)B * (H / 4) * (W / 4);
-    const unsigned grid = (unsigned)((M + TOK_WG - 1) / TOK_WG);
-    PSWIN_CHECK_ARG((long long)grid * TNW * PART3 <= (long long)pswin_stem_workspace(B, H, W));
-    hipLaunchKernelGGL(stem_conv3_bwd_kernel<false>, dim3(grid), dim3(TWG), 0, (hipStream_t)stream, dtok, y2, prm, w3t, H, W, M,
+    const long long groups = (M + TOK_WG - 1) / TOK_WG;
+    const unsigned grid = (unsigned)(groups < 256 ? groups : 256);          // persistent: one workgroup per CU
+    PSWIN_CHECK_ARG((long long)grid * TNW * PART3 <= (long long)pswin_stem_workspace(B, H, W) && M * (long long)(C3 * 2) < 0xFFFFFF00ll);
+    static std::atomic<unsigned long long> configured{0};
+    if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&stem_conv3_bwd_kernel<false>), W3H_BYTES, configured)) return rc;
+    hipLaunchKernelGGL(stem_conv3_bwd_kernel<false>, dim3(grid), dim3(TWG), W3H_BYTES, (hipStream_t)stream, dtok, y2, prm, w3t, H, W, M,
                        (long long)B * H * W * 128, nullptr, workspace);
     launch_colsum(workspace, (int)grid * TNW, PART3, sums, (hipStream_t)stream);
     PSWIN_LAUNCH_RET();
@@ -758,8 +814,12 @@ int pswin_stem_conv3_bwd_data(const void* dtok, const void* y2, const float* prm
                               void* dy2, void* stream) {
     PSWIN_CHECK_ARG(dtok && y2 && prm && w3t && dy2 && B > 0 && H > 0 && W > 0 && H % 4 == 0 && W % 4 == 0);
     const long long M = (long long)B * (H / 4) * (W / 4);
-    const unsigned grid = (unsigned)((M + TOK_WG - 1) / TOK_WG);
-    hipLaunchKernelGGL(stem_conv3_bwd_kernel<true>, dim3(grid), dim3(TWG), 0, (hipStream_t)stream, dtok, y2, prm, w3t, H, W, M,
+    const long long groups = (M + TOK_WG - 1) / TOK_WG;
+    const unsigned grid = (unsigned)(groups < 256 ? groups : 256);
+    PSWIN_CHECK_ARG(M * (long long)(C3 * 2) < 0xFFFFFF00ll);
+    static std::atomic<unsigned long long> configured{0};
+    if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&stem_conv3_bwd_kernel<true>), W3H_BYTES, configured)) return rc;
+    hipLaunchKernelGGL(stem_conv3_bwd_kernel<true>, dim3(grid), dim3(TWG), W3H_BYTES, (hipStream_t)stream, dtok, y2, prm, w3t, H, W, M,
                        (long long)B * H * W * 128, dy2, nullptr);
     PSWIN_LAUNCH_RET();
 }
