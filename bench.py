@@ -77,7 +77,7 @@ TIMED = ("pswin_win_attn_fused_fwd", "pswin_qkv_attn_fused_fwd", "pswin_attn_fwd
          "pswin_stem_conv2_bwd", "lib_gemm_fwd", "lib_gemm_dgrad", "lib_gemm_wgrad")
 # hardware MFMA-pipe utilisation of the window-attention kernels: SQ_VALU_MFMA_BUSY_CYCLES of a separate rocprofv3 --pmc pass
 # (tools/pmc_fused.py / tools/pmc_attn.py), summarised into this committed file; the bench line quotes it with its source
-MFMA_BUSY_FILE = "profiles/r03_pmc_window_attention_mfma.json"
+MFMA_BUSY_FILE = "profiles/r04_pmc_window_attention_mfma.json"
 
 
 def cpu_baseline(threads):
