@@ -94,7 +94,7 @@ struct TnJob {
     void* part;
     float* db;
     int M, N, K, tiles_k, tiles_n, rows_per_split, zero_lo, zero_hi;
-    int first_wg, n_wg, out_bf16, pad_;
+    int first_wg, n_wg, flags, xmap;                   // flags = out_bf16 | splits << 1;  xmap = g | gn << 8 | bk << 16 | bn << 24 (below)
 };
 constexpr int TN_JOBS_MAX = 48;                        // 48 x 80 B: the kernel-argument segment holds 4 KB
 struct TnBatch {
@@ -114,15 +114,15 @@ __global__ __launch_bounds__(RING_THREADS, 2) void gemm_tn_ring_kernel(const TnB
         else jhi = mid - 1;
     }
     const TnJob& job = batch.job[jlo];
-    const int jbid = (int)blockIdx.x - job.first_wg, nwg = job.n_wg;
-    if (jbid >= nwg) return;
+    const int jbid = (int)blockIdx.x - job.first_wg;
+    if (jbid >= job.n_wg) return;
     const unsigned short* __restrict__ DY = job.dy;
     const unsigned short* __restrict__ X = job.x;
     void* __restrict__ P = job.part;
     float* __restrict__ DB = job.db;
     const int M = job.M, N = job.N, K = job.K, tiles_k = job.tiles_k, tiles_n = job.tiles_n, rows_per_split = job.rows_per_split;
     const int zero_lo = job.zero_lo, zero_hi = job.zero_hi;
-    const bool out_bf16 = job.out_bf16 != 0;
+    const bool out_bf16 = (job.flags & 1) != 0;
     constexpr int IA = 6, JB = 3;                      // 16-wide tiles per wave along k (96 columns) / n (48 columns)
     constexpr int RING_STAGE_BYTES = G::STAGE_BYTES, LOADS = G::LOADS;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -131,14 +131,22 @@ __global__ __launch_bounds__(RING_THREADS, 2) void gemm_tn_ring_kernel(const TnB
     const int c = lane & 15, g = lane >> 4;
     const int wk = wave / WN, wn = wave - wk * WN;
 
-    const int ntiles = tiles_k * tiles_n;
-    int t;
+    // Workgroup -> (row split, tile), XCD-aware (workgroup b of a launch runs on XCD b % 8, each XCD with an L2 of its own; measured per
+    // product with FETCH_SIZE, profiles/r04_tn_ring_fetch_per_product.txt: the tiles of a row split that run on ONE XCD fetch its rows once,
+    // every further XCD that holds tiles of the split fetches them again).  A split is given to g = 1, 2, 4 or 8 XCDs (1 when there are at
+    // least 8 splits: XCD x takes the splits x, x + 8, ...); with g > 1 the split's tile grid is cut into gk x gn blocks of bk x bn tiles,
+    // one block per XCD, the cut chosen on the host for the fewest operand columns fetched.  Slots past a block's edge or past the last
+    // split leave at once.
+    int split, tk, tn;
     {
-        const int bid = jbid, q = nwg / 8, r = nwg % 8, xcd = bid % 8, loc = bid / 8;
-        t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
+        const int xm = job.xmap, g = xm & 255, gn = (xm >> 8) & 255, bk = (xm >> 16) & 255, bn = (xm >> 24) & 255;
+        const int xcd = jbid & 7, loc = jbid >> 3, lane = xcd / g, blk = xcd - lane * g, ik = blk / gn, in = blk - ik * gn;
+        const int per = bk * bn, round = loc / per, within = loc - round * per, wk_ = within / bn;
+        split = round * (8 / g) + lane;
+        tk = ik * bk + wk_;
+        tn = in * bn + (within - wk_ * bn);
+        if (split >= (job.flags >> 1) || tk >= tiles_k || tn >= tiles_n) return;
     }
-    const int split = t / ntiles, tile = t - split * ntiles;
-    const int tk = tile / tiles_n, tn = tile - tk * tiles_n;
     const int k0 = tk * (96 * WK), n0 = tn * (48 * WN);
     const int m_begin = split * rows_per_split;
     int steps = rows_per_split / MSTEP;
@@ -373,10 +381,29 @@ int launch_tn_jobs(const pswin_tn_job* jobs, int n_jobs, int geom, hipStream_t s
         j.zero_lo = q.zero_lo;
         j.zero_hi = q.zero_hi;
         j.first_wg = (int)wgs;
-        j.n_wg = j.tiles_k * j.tiles_n * q.splits;
-        j.out_bf16 = q.partial_dtype == PSWIN_BF16;
-        j.pad_ = 0;
-        wgs += (j.n_wg + 7) / 8 * 8;
+        {
+            // XCDs per split and the cut of its tile grid (kernel comment): cost of a cut = operand columns fetched by the g XCDs
+            const int S = q.splits;
+            int g = 1;
+            if (S < 8) {
+                int p2 = 1;
+                while (p2 < S) p2 *= 2;
+                g = 8 / p2;
+            }
+            int best_gn = 1;
+            long long best = -1;
+            for (int gn = 1; gn <= g; gn *= 2) {
+                const int gk = g / gn;
+                const long long cost = (long long)((j.tiles_k + gk - 1) / gk) * tk + (long long)((j.tiles_n + gn - 1) / gn) * tn;
+                if (best < 0 || cost < best) best = cost, best_gn = gn;
+            }
+            const int gn = best_gn, gk = g / gn, bk = (j.tiles_k + gk - 1) / gk, bn = (j.tiles_n + gn - 1) / gn;
+            const int lanes = 8 / g, rounds = (S + lanes - 1) / lanes;
+            j.xmap = g | gn << 8 | bk << 16 | bn << 24;
+            j.n_wg = 8 * rounds * bk * bn;
+        }
+        j.flags = (q.partial_dtype == PSWIN_BF16 ? 1 : 0) | q.splits << 1;
+        wgs += j.n_wg;
         if (++b.n == TN_JOBS_MAX || wgs > (1ll << 24)) {
             if (const int rc = flush()) return rc;
         }

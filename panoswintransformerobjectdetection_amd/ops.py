@@ -795,8 +795,14 @@ GROUPED_WGRAD_ROWS = int(os.environ.get("PSWIN_GROUPED_WGRAD_ROWS", "2048"))
 
 
 def grouped_wgrad_splits(M):
-    """row splits of one weight gradient inside the grouped launch: about GROUPED_WGRAD_ROWS rows per workgroup"""
-    return max(1, min(M // 64, (M + GROUPED_WGRAD_ROWS // 2) // GROUPED_WGRAD_ROWS))
+    """row splits of one weight gradient inside the grouped launch: about GROUPED_WGRAD_ROWS rows per workgroup, in counts that divide
+    over the 8 XCDs (1, 2, 4 or a multiple of 8: the kernel gives a split to 8, 4, 2 XCDs or one, csrc/pswin_gemm_tn.hip)"""
+    s = max(1, min(M // 64, (M + GROUPED_WGRAD_ROWS // 2) // GROUPED_WGRAD_ROWS))
+    if s >= 6:
+        s = max(8, (s + 4) // 8 * 8)
+    elif s >= 3:
+        s = 4
+    return max(1, min(M // 64, s))
 
 
 def queue_weight_gradient(dy, x, weight, bias, zero_cols):
