@@ -751,7 +751,7 @@ int pswin_stem_workspace(int B, int H, int W) {
     long long n = 512ll * t8::NW * t8::PART1;   // statistics pass: 512 workgroups of t8::NW waves
     const long long f2 = 256ll * t16::NW * t16::PART2;
     n = n > f2 ? n : f2;
-    const long long a = ((M + TOK_WG - 1) / TOK_WG) * TNW * PART3, b = 64ll * 4 * WG3_OUT, c2 = 512ll * t8::WG2_OUT;
+    const long long a = ((M + TOK_WG - 1) / TOK_WG) * TNW * PART3, b = 128ll * 4 * WG3_OUT, c2 = 512ll * t8::WG2_OUT;
     n = n > a ? n : a;
     n = n > b ? n : b;
     n = n > c2 ? n : c2;
@@ -830,7 +830,8 @@ int pswin_stem_conv3_wgrad(const void* dtok, const void* y2, const float* scale2
     const long long M = (long long)B * (H / 4) * (W / 4);
     PSWIN_CHECK_ARG(M < 0x7fffffffll - 64);
     const int nsteps = (int)((M + 31) / 32);
-    int splits = nsteps < 64 ? nsteps : 64;          // workgroups per tap row
+    int splits = nsteps < 128 ? nsteps : 128;        // workgroups per tap row: 512 in all = two per CU (126 registers, 47 KB of LDS each) -- with one, a
+                                                     // CU has a single 22 KB step in flight and the kernel runs at 2.8 TB/s (bytes in flight / latency)
     const int per = (nsteps + splits - 1) / splits;
     splits = (nsteps + per - 1) / per;
     PSWIN_CHECK_ARG((long long)splits * 4 * WG3_OUT <= (long long)pswin_stem_workspace(B, H, W));
