@@ -124,6 +124,13 @@ int pswin_window_scatter_add(const void* win, int win_dtype, const int32_t* inv,
 int pswin_ln_gather_fwd(const void* x, int x_dtype, const int32_t* map, const float* gamma, const float* beta, float eps,
                         void* y, int y_dtype, float* mean, float* rstd, int B, int S, int n_out, int C, void* stream);
 
+/* The same with one more f32 row added to every normalised row: y[b][t][:] = LN(x[b][t][:]) * gamma + beta + add_rows[t][:].
+ * add_rows: f32 [S, C] (NULL: nothing added) -- the absolute position encoding of HOT:926-934 (abs_encoder(xyzuv), the same for
+ * every image) added to the PatchEmbed.norm output (HOT:771, 934) in the pass that writes it; map must be NULL with add_rows. */
+int pswin_ln_gather_fwd_add(const void* x, int x_dtype, const int32_t* map, const float* gamma, const float* beta, float eps,
+                            const float* add_rows, void* y, int y_dtype, float* mean, float* rstd, int B, int S, int n_out, int C,
+                            void* stream);
+
 /* Its backward: for every token (b, t), dy row = dy[b][inv ? inv[t] : t] and
  *   dx = rstd * (g - mean(g) - xhat * mean(g * xhat)),  g = dy * gamma, xhat = (x - mean) * rstd;
  *   dgamma = sum dy * xhat, dbeta = sum dy (block partials in `workspace`, reduced in a fixed order).
@@ -357,7 +364,7 @@ typedef struct pswin_transpose_job {
 int pswin_transpose_jobs(const pswin_transpose_job* jobs, int n_jobs, void* stream);
 
 /* AdamW over the one flat fp32 parameter buffer of a model: the update that ends every training step of the path (the reference runs
- * torch.optim.AdamW through mmcv's OptimizerHook, mmdet/apis/train.py:91-112 with configs/swin/*.py: lr 1e-4, betas (0.9, 0.999),
+ * torch.optim.AdamW through mmcv's OptimizerHook, mmdet/apis/train.py:91-112 with the configs/swin files: lr 1e-4, betas (0.9, 0.999),
  * weight_decay 0.05), fused with the bf16 copy of the updated parameters that the next step's kernels read.  p, g, m, v: f32 [n]
  * (n a multiple of 4, 16-byte aligned); p_bf16: bf16 [n] or NULL; step: DEVICE pointer to the number (>= 1, as a float) of the step being
  * taken.  Same arithmetic, element by element, as torch.optim.AdamW. */
@@ -407,6 +414,9 @@ int pswin_nms_groups(const float* boxes, const int32_t* counts, int groups, int 
 
 int pswin_gemm_nt_supported(long long M, int K, int N);
 int pswin_gemm_nt(const void* x, const void* w, const float* bias, void* y, long long M, int K, int N, int tile_m, void* stream);
+/* The same product with an f32 result (y: f32 [M, N], M * N * 4 < 4 GiB): PatchMerging.reduction (HOT:575), whose output is the fp32
+ * residual stream of the next stage -- written once instead of as bf16 plus a cast. */
+int pswin_gemm_nt_f32(const void* x, const void* w, const float* bias, float* y, long long M, int K, int N, int tile_m, void* stream);
 /* The data gradient of the Mlp's fc2 fused with the backward of fc1's bias + nn.GELU (HOT:50-58):
  *   dpre[M, N] = (dy[M, K] . w_t[N, K]^T) * gelu'(pre + bias),   partial[t][n] = sum over the rows of row tile t of dpre[., n]
  * with w_t = fc2.weight^T ([hidden N, K]), pre = the pre-activation fc1(x) without bias, bias = fc1.bias (f32 [N] or NULL).

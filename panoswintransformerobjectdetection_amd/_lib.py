@@ -29,6 +29,7 @@ _PROTOTYPES = {
     "pswin_window_gather": [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "pswin_window_scatter_add": [_vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "pswin_ln_gather_fwd": [_vp, _i, _vp, _vp, _vp, _f, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
+    "pswin_ln_gather_fwd_add": [_vp, _i, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],
     "pswin_ln_gather_bwd": [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "pswin_ln_gather_bwd_ex": [_vp, _i, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i,
                                _vp],
@@ -75,6 +76,7 @@ _PROTOTYPES = {
     "pswin_nms_groups": [_vp, _vp, _i, _i, ctypes.c_float, _vp, _vp, _vp],
     "pswin_gemm_nt_supported": [ctypes.c_longlong, _i, _i],
     "pswin_gemm_nt": [_vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _i, _vp],
+    "pswin_gemm_nt_f32": [_vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _i, _vp],
     "pswin_gemm_nt_gelu_fwd": [_vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _i, _vp],
     "pswin_gemm_nt_partial_rows": [ctypes.c_longlong, _i],
     "pswin_gemm_nt_gelu_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, ctypes.c_longlong, _i, _i, _i, _vp],

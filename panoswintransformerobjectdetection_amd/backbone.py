@@ -294,7 +294,8 @@ class PatchMerging(nn.Module):
         B, S, C = x.shape
         assert S == H * W, "input feature has wrong size"
         g = ops.layer_norm_patch_merge(x, self.norm.weight, self.norm.bias, self.norm.eps, H, W, cd)
-        return _linear(g, self.reduction, cd).to(x.dtype)
+        # the fp32 residual stream of the next stage straight from the GEMM's epilogue (pswin_gemm_nt_f32) where the tiled kernel runs
+        return _linear(g, self.reduction, cd, out_f32=(x.dtype == torch.float32)).to(x.dtype)
 
 
 class BasicLayer(nn.Module, DoubleModeModule):
@@ -373,6 +374,24 @@ class _ApeAdd(torch.autograd.Function):
         return g, None, dw, db
 
 
+class _ApeRows(torch.autograd.Function):
+    """Linear(feat) [S, C] alone: the rows PatchEmbed's LayerNorm kernel adds while it writes the residual stream
+    (ops.layer_norm_gather(add_rows=...)) -- the same arithmetic as _ApeAdd without the pass over [B, S, C]; the gradient it
+    receives is already summed over the batch."""
+
+    @staticmethod
+    def forward(ctx, feat, weight, bias):
+        ctx.save_for_backward(feat)
+        ctx.bias = bias
+        return F.linear(feat, weight, bias)
+
+    @staticmethod
+    def backward(ctx, gs):
+        feat, = ctx.saved_tensors
+        gs = gs.contiguous()
+        return None, gs.t() @ feat, ops.colsum(gs, owners=(ctx.bias,))
+
+
 class _ChannelBias(torch.autograd.Function):
     """y + bias over the channel dim of a channels-last NCHW tensor; the bias gradient is a column sum over the
     [N*H*W, C] row view (pswin_colsum).  Keeps the convolution bias out of MIOpen's ConvolutionBackwardBias, whose
@@ -403,7 +422,9 @@ class PatchEmbed(nn.Module):
             nn.Conv2d(c * 2, embed_dim, kernel_size=self.patch_size, stride=self.patch_size))
         self.norm = nn.LayerNorm(embed_dim) if norm else None
 
-    def forward(self, x, cd=torch.float32):
+    def forward(self, x, cd=torch.float32, add_rows=None):
+        """add_rows: a callable (Wh, Ww) -> f32 [Wh * Ww, C] rows added to the normalised tokens inside the LayerNorm kernel (the
+        absolute position encoding); it is used -- and the third return value True -- only where that kernel runs."""
         _, _, H, W = x.shape
         ph, pw = self.patch_size
         if W % pw:
@@ -414,8 +435,10 @@ class PatchEmbed(nn.Module):
             B, Wh, Ww = x.shape[0], x.shape[2] // ph, x.shape[3] // pw    # full-resolution tensor ever stored
             tok = stem.stem_forward(self.proj, x, self.training).view(B, Wh * Ww, self.embed_dim)
             if self.norm is not None:
-                tok = ops.layer_norm_gather(tok, self.norm.weight, self.norm.bias, self.norm.eps, out_dtype=torch.float32)
-            return tok.float(), Wh, Ww
+                rows = add_rows(Wh, Ww) if add_rows is not None else None
+                tok = ops.layer_norm_gather(tok, self.norm.weight, self.norm.bias, self.norm.eps, out_dtype=torch.float32, add_rows=rows)
+                return (tok.float(), Wh, Ww, True) if add_rows is not None else (tok.float(), Wh, Ww)
+            return (tok.float(), Wh, Ww, False) if add_rows is not None else (tok.float(), Wh, Ww)
         with torch.autocast("cuda", dtype=torch.bfloat16, enabled=(cd == torch.bfloat16)):
             x = x.contiguous(memory_format=torch.channels_last)                 # bf16: MIOpen NHWC bf16 convolutions
             mods = list(self.proj)
@@ -439,8 +462,10 @@ class PatchEmbed(nn.Module):
         B, C, Wh, Ww = x.shape
         tok = x.permute(0, 2, 3, 1).reshape(B, Wh * Ww, C)          # free for a channels-last tensor
         if self.norm is not None:                                    # reads bf16 or fp32, writes the fp32 residual stream
-            tok = ops.layer_norm_gather(tok, self.norm.weight, self.norm.bias, self.norm.eps, out_dtype=torch.float32)
-        return tok.float(), Wh, Ww
+            rows = add_rows(Wh, Ww) if add_rows is not None else None
+            tok = ops.layer_norm_gather(tok, self.norm.weight, self.norm.bias, self.norm.eps, out_dtype=torch.float32, add_rows=rows)
+            return (tok.float(), Wh, Ww, True) if add_rows is not None else (tok.float(), Wh, Ww)
+        return (tok.float(), Wh, Ww, False) if add_rows is not None else (tok.float(), Wh, Ww)
 
 
 @BACKBONES.register_module()
@@ -629,10 +654,14 @@ class SimplePanoSwinTransformer(nn.Module, DoubleModeModule):
         cd = self.compute_dtype
         if cd != torch.float32:
             self._refresh_lowp(cd, for_backward=torch.is_grad_enabled())
-        x, Wh, Ww = self.patch_embed(x_bchw.float(), cd)
-        if self.pano_mode and self.ape:
-            feat = ops.abs_pos_features(Wh, Ww, x.device)                               # HOT:926-934
-            x = _ApeAdd.apply(x, feat, self.abs_encoder.weight, self.abs_encoder.bias)
+        if self.pano_mode and self.ape:                                                  # HOT:926-934
+            dev = x_bchw.device
+            x, Wh, Ww, added = self.patch_embed(x_bchw.float(), cd, add_rows=lambda h, w: _ApeRows.apply(
+                ops.abs_pos_features(h, w, dev), self.abs_encoder.weight, self.abs_encoder.bias))
+            if not added:                                                                # no PatchEmbed.norm to carry the addition
+                x = _ApeAdd.apply(x, ops.abs_pos_features(Wh, Ww, dev), self.abs_encoder.weight, self.abs_encoder.bias)
+        else:
+            x, Wh, Ww = self.patch_embed(x_bchw.float(), cd)
         if self.drop_rate > 0.:
             x = F.dropout(x, self.drop_rate, self.training)                              # pos_drop (HOT:967), features only
         outs = []

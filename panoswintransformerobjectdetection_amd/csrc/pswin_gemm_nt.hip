@@ -199,8 +199,8 @@ __global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_kernel(const unsigned s
     }
 
     // acc[i][j][e] = Y[row m0 + wm * BM/2 + 16 i + c][column n0 + wn * 96 + 16 j + 4 g + e]
-    const rsrc_t ys = __builtin_amdgcn_make_buffer_rsrc(Y, 0, (int)((size_t)M * N * 2), 0x00020000);
-    if constexpr (EPI == 0 || EPI == 2) {
+    const rsrc_t ys = __builtin_amdgcn_make_buffer_rsrc(Y, 0, (int)((size_t)M * N * (EPI == 3 ? 4 : 2)), 0x00020000);
+    if constexpr (EPI == 0 || EPI == 2 || EPI == 3) {
         const rsrc_t hs = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(aux), 0, EPI == 2 ? (int)((size_t)M * N * 2) : 0, 0x00020000);
         // the bias values of this lane's columns are loaded before the first store: a load issued behind stores waits for them
         // (one in-order counter), which made every row tile of the epilogue a memory round trip
@@ -220,11 +220,18 @@ __global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_kernel(const unsigned s
 #pragma unroll
             for (int jp = 0; jp < CT / 2; ++jp) {
                 f32x4 q0 = acc[i][2 * jp], q1 = acc[i][2 * jp + 1];
-                if constexpr (EPI == 0) {
+                if constexpr (EPI == 0 || EPI == 3) {
                     q0 += bq[jp][0];
                     q1 += bq[jp][1];
                 }
                 const unsigned off = base == 0xFFFFFF00u ? base : base + 64u * jp;
+                if constexpr (EPI == 3) {             // f32 output (Y is float*): the same 8 consecutive columns as two 16-byte stores
+                    exchange_row8(q0, q1);
+                    const unsigned off4 = off == 0xFFFFFF00u ? off : 2u * off;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q0), ys, off4, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, q1), ys, off4 == 0xFFFFFF00u ? off4 : off4 + 16u, 0, 0);
+                    continue;
+                }
                 const u32x4 yp = pack_row8(q0, q1);
                 __builtin_amdgcn_raw_buffer_store_b128(yp, ys, off, 0, 0);
                 if constexpr (EPI == 2) {
@@ -327,6 +334,17 @@ int pswin_gemm_nt(const void* x, const void* w, const float* bias, void* y, long
     if (tile_m == 0) tile_m = ((long long)((m + 127) / 128) * (N / BN) >= 512) ? 128 : 64;
     if (tile_m == 128) return launch_nt<128, 0>(x, w, bias, y, m, N, K, (hipStream_t)stream);
     return launch_nt<64, 0>(x, w, bias, y, m, N, K, (hipStream_t)stream);
+}
+
+/* the same product written as f32 (y: f32 [M, N]): for a Linear whose result joins the fp32 residual stream (PatchMerging.reduction) */
+int pswin_gemm_nt_f32(const void* x, const void* w, const float* bias, float* y, long long M, int K, int N, int tile_m, void* stream) {
+    PSWIN_CHECK_ARG(x && w && y && pswin_gemm_nt_supported(M, K, N) && M * (long long)N * 4 < 0xFFFFFF00ll &&
+                    (tile_m == 0 || tile_m == 64 || tile_m == 128));
+    PSWIN_CHECK_ARG(aligned16(x) && aligned16(w) && aligned16(y) && aligned16(bias));
+    const int m = (int)M;
+    if (tile_m == 0) tile_m = ((long long)((m + 127) / 128) * (N / BN) >= 512) ? 128 : 64;
+    if (tile_m == 128) return launch_nt<128, 3>(x, w, bias, y, m, N, K, (hipStream_t)stream);
+    return launch_nt<64, 3>(x, w, bias, y, m, N, K, (hipStream_t)stream);
 }
 
 int pswin_gemm_nt_partial_rows(long long M, int tile_m) {

@@ -67,7 +67,8 @@ __global__ __launch_bounds__(THREADS) void ln_fwd_kernel(const void* __restrict_
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float eps,
                                                          void* __restrict__ y, float* __restrict__ mean,
-                                                         float* __restrict__ rstd, long long rows, int C) {
+                                                         float* __restrict__ rstd, long long rows, int C,
+                                                         const float* __restrict__ add) {
     constexpr int RPB = THREADS / L;
     const int lane = threadIdx.x % L;
     const long long row = (long long)blockIdx.x * RPB + threadIdx.x / L;
@@ -115,7 +116,11 @@ __global__ __launch_bounds__(THREADS) void ln_fwd_kernel(const void* __restrict_
         if (ch < nchunks) {
             const f32x4 g4 = *reinterpret_cast<const f32x4*>(gamma + 4 * ch);
             const f32x4 b4 = *reinterpret_cast<const f32x4*>(beta + 4 * ch);
-            store4<YDT>(y, (size_t)row * C + 4 * (size_t)ch, (v[k] - mu) * rs_ * g4 + b4);
+            f32x4 o = (v[k] - mu) * rs_ * g4 + b4;
+            // add: one more f32 row per output row of an image ([n_out, C]: the absolute position encoding, HOT:932-934, added to the
+            // normalised patch embedding while it is in registers instead of by a pass over the residual stream)
+            if (add) o = o + *reinterpret_cast<const f32x4*>(add + (size_t)r * C + 4 * (size_t)ch);
+            store4<YDT>(y, (size_t)row * C + 4 * (size_t)ch, o);
         }
     }
     if (lane == 0) {
@@ -578,17 +583,17 @@ inline int bwd_blocks(long long rows, int L) {
 
 template <int MODE, int XDT, int YDT>
 int launch_fwd(int L, const void* x, const RowSrc& rs, const float* gamma, const float* beta, float eps, void* y,
-               float* mean, float* rstd, long long rows, int C, hipStream_t st) {
+               float* mean, float* rstd, long long rows, int C, hipStream_t st, const float* add = nullptr) {
 #define PSWIN_LN_FWD(LL)                                                                                          \
     case LL: {                                                                                                    \
         const int rpb = THREADS / LL;                                                                             \
         hipLaunchKernelGGL((ln_fwd_kernel<MODE, XDT, YDT, LL, 4>), dim3((unsigned)((rows + rpb - 1) / rpb)),      \
-                           dim3(THREADS), 0, st, x, rs, gamma, beta, eps, y, mean, rstd, rows, C);                \
+                           dim3(THREADS), 0, st, x, rs, gamma, beta, eps, y, mean, rstd, rows, C, add);           \
         break;                                                                                                    \
     }
     if (wide_row(C)) {
         hipLaunchKernelGGL((ln_fwd_kernel<MODE, XDT, YDT, 64, 8>), dim3((unsigned)((rows + 3) / 4)), dim3(THREADS), 0,
-                           st, x, rs, gamma, beta, eps, y, mean, rstd, rows, C);
+                           st, x, rs, gamma, beta, eps, y, mean, rstd, rows, C, add);
         PSWIN_LAUNCH_RET();
     }
     switch (L) {
@@ -659,20 +664,27 @@ extern "C" int pswin_ln_partial_rows(long long rows, int C) {
     return bwd_blocks(rows, pick_lanes(C));
 }
 
-extern "C" int pswin_ln_gather_fwd(const void* x, int x_dtype, const int32_t* map, const float* gamma,
-                                   const float* beta, float eps, void* y, int y_dtype, float* mean, float* rstd, int B,
-                                   int S, int n_out, int C, void* stream) {
+extern "C" int pswin_ln_gather_fwd_add(const void* x, int x_dtype, const int32_t* map, const float* gamma,
+                                       const float* beta, float eps, const float* add_rows, void* y, int y_dtype, float* mean,
+                                       float* rstd, int B, int S, int n_out, int C, void* stream) {
     PSWIN_CHECK_ARG(x && gamma && beta && y && mean && rstd && B > 0 && S > 0 && n_out > 0);
     PSWIN_CHECK_ARG(valid_dtype(x_dtype) && valid_dtype(y_dtype));
     PSWIN_CHECK_ARG(C >= 8 && C % 8 == 0 && C <= MAX_C && aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta));
     PSWIN_CHECK_ARG(map || n_out == S);
+    PSWIN_CHECK_ARG(!add_rows || (!map && aligned16(add_rows)));      // the added rows follow the token order of an image
     RowSrc rs = {0, map, S, n_out, 0, 0, 0};
     const long long rows = (long long)B * n_out;
     const int L = pick_lanes(C);
     return dispatch2(x_dtype, y_dtype, [&](auto xd, auto yd) {
         return launch_fwd<0, decltype(xd)::value, decltype(yd)::value>(L, x, rs, gamma, beta, eps, y, mean, rstd, rows,
-                                                                       C, (hipStream_t)stream);
+                                                                       C, (hipStream_t)stream, add_rows);
     });
+}
+
+extern "C" int pswin_ln_gather_fwd(const void* x, int x_dtype, const int32_t* map, const float* gamma,
+                                   const float* beta, float eps, void* y, int y_dtype, float* mean, float* rstd, int B,
+                                   int S, int n_out, int C, void* stream) {
+    return pswin_ln_gather_fwd_add(x, x_dtype, map, gamma, beta, eps, nullptr, y, y_dtype, mean, rstd, B, S, n_out, C, stream);
 }
 
 extern "C" int pswin_scatter_add_ln_fwd_map(const void* win, int win_dtype, const int32_t* inv, const float* resid,

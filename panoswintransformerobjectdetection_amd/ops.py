@@ -432,16 +432,25 @@ def patch_merge_gather(x, H, W, out_dtype=None):
 
 class _LayerNormGather(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, wmap, inv, out_dtype, passthrough, res_bias, res_scale):
+    def forward(ctx, x, gamma, beta, eps, wmap, inv, out_dtype, passthrough, res_bias, res_scale, add_rows=None):
         B, S, C = x.shape
         x = x.contiguous()
         n_out = S if wmap is None else wmap.numel()
         y = torch.empty(B, n_out, C, dtype=out_dtype, device=x.device)
         mean = torch.empty(B, S, dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
-        call("pswin_ln_gather_fwd", x, ptr(x), dtype_code(x), ptr(wmap), ptr(gamma), ptr(beta), float(eps), ptr(y),
-             dtype_code(y), ptr(mean), ptr(rstd), B, S, n_out, C,
-             algo_bytes=B * C * (min(S, n_out) * x.element_size() + n_out * y.element_size()))
+        if add_rows is None:
+            call("pswin_ln_gather_fwd", x, ptr(x), dtype_code(x), ptr(wmap), ptr(gamma), ptr(beta), float(eps), ptr(y),
+                 dtype_code(y), ptr(mean), ptr(rstd), B, S, n_out, C,
+                 algo_bytes=B * C * (min(S, n_out) * x.element_size() + n_out * y.element_size()))
+        else:
+            if wmap is not None or add_rows.shape != (S, C) or add_rows.dtype != torch.float32 or passthrough:
+                raise PswinError("layer_norm_gather(add_rows=...) takes f32 [S, C] rows, no window map and no passthrough")
+            add_rows = add_rows.contiguous()
+            call("pswin_ln_gather_fwd_add", x, ptr(x), dtype_code(x), None, ptr(gamma), ptr(beta), float(eps), ptr(add_rows), ptr(y),
+                 dtype_code(y), ptr(mean), ptr(rstd), B, S, n_out, C, timed_as="pswin_ln_gather_fwd",
+                 algo_bytes=B * C * (S * x.element_size() + n_out * y.element_size()) + 4 * S * C)
+        ctx.has_add = add_rows is not None
         ctx.save_for_backward(x, gamma, mean, rstd, inv, res_scale)
         ctx.n_out = n_out
         ctx.want_res_sum = res_bias is not None
@@ -466,7 +475,7 @@ class _LayerNormGather(torch.autograd.Function):
             if ctx.want_res_sum:
                 g = dres if res_scale is None else dres * res_scale[:, None, None]
                 dres_sum = colsum(g.reshape(-1, C), owners=ctx.owners[2:])
-            return dres, torch.zeros_like(gamma), torch.zeros_like(gamma), None, None, None, None, None, dres_sum, None
+            return dres, torch.zeros_like(gamma), torch.zeros_like(gamma), None, None, None, None, None, dres_sum, None, None
         dy = dy.contiguous()
         lib = _lib.load()
         ws = torch.empty(lib.pswin_ln_workspace(B * S, C), dtype=torch.float32, device=x.device)
@@ -478,11 +487,13 @@ class _LayerNormGather(torch.autograd.Function):
         sums = sum_rows(ws, lib.pswin_ln_partial_rows(B * S, C), nseg * C, owners=ctx.owners)
         if ctx.want_res_sum:
             dres_sum = sums[2 * C:]
-        return dx, sums[:C], sums[C:2 * C], None, None, None, None, None, dres_sum, None
+        # the added rows' gradient: a per-element sum over the batch (one pass, no framework two-pass reduction)
+        dadd = (dy.float().sum(0) if B > 1 else dy[0].float()) if ctx.has_add else None
+        return dx, sums[:C], sums[C:2 * C], None, None, None, None, None, dres_sum, None, dadd
 
 
 def layer_norm_gather(x, gamma, beta, eps, wmap=None, inv=None, out_dtype=None, passthrough=False, res_bias=None,
-                      res_scale=None):
+                      res_scale=None, add_rows=None):
     """LayerNorm over the last dim of x [B, S, C], written through a window map (norm1 + shift + pad + window
     partition, HOT:503-513) or in place order (wmap=None: norm2 / output norms).  Padding slots are zero rows.
 
@@ -493,6 +504,8 @@ def layer_norm_gather(x, gamma, beta, eps, wmap=None, inv=None, out_dtype=None, 
     res_bias (with passthrough): the bias b of the branch x' + scale_b * (f(y) + b) that window_scatter_add(...,
     bias=b, bias_grad_elsewhere=True) adds; its gradient, sum_{b,t} res_scale[b] * grad(x')[b][t], is accumulated by
     the same backward kernel (which reads grad(x') anyway) and returned here."""
+    if add_rows is not None:        # + f32 [S, C] rows after the affine (the absolute position encoding): pswin_ln_gather_fwd_add
+        return _LayerNormGather.apply(x, gamma, beta, eps, wmap, inv, out_dtype or x.dtype, passthrough, res_bias, res_scale, add_rows)
     return _LayerNormGather.apply(x, gamma, beta, eps, wmap, inv, out_dtype or x.dtype, passthrough, res_bias, res_scale)
 
 
@@ -872,13 +885,18 @@ def gemm_tn_ring(dy, x, splits, out_dtype=torch.float32, bias_sums=False, zero_c
     return part, dbp
 
 
-def gemm_nt(x2d, w, bias=None, tile_m=0):
-    """y = x2d @ w^T (+ bias): x2d [M, K] bf16, w [N, K] bf16, bias f32 [N] or None -> [M, N] bf16."""
+def gemm_nt(x2d, w, bias=None, tile_m=0, out_f32=False):
+    """y = x2d @ w^T (+ bias): x2d [M, K] bf16, w [N, K] bf16, bias f32 [N] or None -> [M, N] bf16 (out_f32: f32, pswin_gemm_nt_f32)."""
     x2d, w = x2d.contiguous(), w.contiguous()
     M, K = x2d.shape
     N = w.shape[0]
-    y = torch.empty(M, N, dtype=torch.bfloat16, device=x2d.device)
     b = None if bias is None else bias.detach().float().contiguous()
+    if out_f32:
+        y = torch.empty(M, N, dtype=torch.float32, device=x2d.device)
+        call("pswin_gemm_nt_f32", x2d, ptr(x2d), ptr(w), ptr(b), ptr(y), M, K, N, int(tile_m), timed_as="pswin_gemm_nt",
+             algo_bytes=2 * (M * K + N * K) + 4 * M * N, algo_flops=2 * M * K * N)
+        return y
+    y = torch.empty(M, N, dtype=torch.bfloat16, device=x2d.device)
     call("pswin_gemm_nt", x2d, ptr(x2d), ptr(w), ptr(b), ptr(y), M, K, N, int(tile_m),
          algo_bytes=2 * (M * K + M * N + N * K), algo_flops=2 * M * K * N)
     return y
@@ -934,7 +952,8 @@ class _LinearSplitK(torch.autograd.Function):
     explicit split-K, 55-75 us) whose fp32 partial sum also removes the bf16 -> fp32 gradient cast."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, w_lp, b_lp, zero_bias_cols=None, w_lp_t=None):
+    def forward(ctx, x, weight, bias, w_lp, b_lp, zero_bias_cols=None, w_lp_t=None, out_f32=False):
+        # out_f32: an f32 result where the tiled HIP GEMM runs (its epilogue writes it), a cast of the bf16 result elsewhere
         # w_lp / b_lp: this step's bf16 copies of the fp32 master parameters (refreshed by ONE multi-tensor cast per
         # forward, see SimplePanoSwinTransformer._refresh_lowp); gradients go to the fp32 masters.
         wb = w_lp if w_lp is not None else weight.to(x.dtype)
@@ -943,21 +962,25 @@ class _LinearSplitK(torch.autograd.Function):
         ctx.zero_bias_cols = zero_bias_cols
         ctx.weight, ctx.bias = weight, bias                 # for grad_slot / owners: dW may be summed straight into its flat slot
         if skinny_gemm_supported(x, wb.shape[0]):       # stage-0 shapes: streaming HIP GEMM, weight resident in LDS
-            return skinny_gemm(x, wb, bias)
+            y = skinny_gemm(x, wb, bias)
+            return y.float() if out_f32 else y
         tile = gemm_nt_tile(x.shape[0], x.shape[1], wb.shape[0]) if x.dtype == torch.bfloat16 else 0
         if tile:                                        # stages 1-3: tiled HIP GEMM where it beats the library kernel
-            return gemm_nt(x, wb, bias, tile)
+            return gemm_nt(x, wb, bias, tile, out_f32=out_f32)
         bb = None if bias is None else (b_lp if b_lp is not None else bias.to(x.dtype))
         M, K, N = x.shape[0], x.shape[1], wb.shape[0]
         with _lib.timed("lib_gemm_fwd", 2 * (M * K + M * N + N * K), 2 * M * K * N):
-            return F.linear(x, wb, bb)
+            y = F.linear(x, wb, bb)
+        return y.float() if out_f32 else y
 
     @staticmethod
     def backward(ctx, dy):
         x, wb, wbt = ctx.saved_tensors
+        if dy.dtype != x.dtype:                             # out_f32: the gradient arrives in fp32
+            dy = dy.to(x.dtype)
         dx, dw, db = linear_backward(x, wb, dy, ctx.weight, ctx.bias if ctx.has_bias else None, ctx.zero_bias_cols,
                                      ctx.needs_input_grad[0], wbt)
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
 def linear_backward(x, wb, dy, weight, bias, zero_bias_cols, need_dx, wbt=None):
@@ -1012,7 +1035,7 @@ def linear_backward(x, wb, dy, weight, bias, zero_bias_cols, need_dx, wbt=None):
     return dx, dw, db
 
 
-def linear(x, lin, cd, use_bias=True, zero_bias_cols=None):
+def linear(x, lin, cd, use_bias=True, zero_bias_cols=None, out_f32=False):
     """nn.Linear on rows.  fp32: F.linear (parity path).  bf16: split-K weight gradient, fp32 parameter gradients.
     use_bias=False: the caller applies lin.bias itself (fused into the next row kernel).  zero_bias_cols=(lo, hi): output
     columns whose gradient sums to zero over the rows (their bias gradient is zero; the column sum skips them)."""
@@ -1024,7 +1047,7 @@ def linear(x, lin, cd, use_bias=True, zero_bias_cols=None):
     w_lp, b_lp = lp if lp is not None else (None, None)
     bias = lin.bias if use_bias else None
     return _LinearSplitK.apply(x2, lin.weight, bias, w_lp, b_lp if use_bias else None, zero_bias_cols,
-                               lin.__dict__.get("_lowp_t")).view(*shp[:-1], lin.weight.shape[0])
+                               lin.__dict__.get("_lowp_t"), out_f32).view(*shp[:-1], lin.weight.shape[0])
 
 
 class _Fc1Gelu(torch.autograd.Function):

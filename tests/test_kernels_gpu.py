@@ -171,6 +171,31 @@ def test_layer_norm_gather_passthrough(ops, C, use_map):
     assert torch.equal(xd.grad, gx)
 
 
+@pytest.mark.parametrize("C,xdt", [(96, torch.bfloat16), (96, torch.float32), (192, torch.bfloat16)])
+def test_layer_norm_gather_with_added_rows_equals_the_separate_addition(ops, C, xdt):
+    """pswin_ln_gather_fwd_add (PatchEmbed.norm + the absolute position rows in one pass): bitwise the LayerNorm followed by the
+    broadcast addition; the rows' gradient is the batch sum of dy, the other gradients are those of the plain LayerNorm."""
+    B, S = 3, 13 * 25
+    x = (det_uniform((B, S, C), "lna:x", 2.0) + 0.3).to(xdt)
+    gamma, beta = det_uniform((C,), "lna:g", 0.5, 1.0), det_uniform((C,), "lna:b", 0.5)
+    rows = det_uniform((S, C), "lna:r", 1.5)
+    gy = det_uniform((B, S, C), "lna:gy").to(DEV)
+    res = []
+    for fused in (False, True):
+        xd = x.to(DEV).requires_grad_(True)
+        gd, bd, rd = gamma.to(DEV).requires_grad_(True), beta.to(DEV).requires_grad_(True), rows.to(DEV).requires_grad_(True)
+        if fused:
+            y = ops.layer_norm_gather(xd, gd, bd, 1e-5, out_dtype=torch.float32, add_rows=rd)
+        else:
+            y = ops.layer_norm_gather(xd, gd, bd, 1e-5, out_dtype=torch.float32) + rd[None]
+        (y * gy).sum().backward()
+        res.append((y.detach(), xd.grad, gd.grad, bd.grad, rd.grad))
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+    with pytest.raises(Exception):
+        ops.layer_norm_gather(x.to(DEV), gamma.to(DEV), beta.to(DEV), 1e-5, out_dtype=torch.float32, add_rows=rows[:-1].to(DEV))
+
+
 @pytest.mark.parametrize("H,W,C", [(5, 7, 32), (16, 32, 96), (8, 16, 384), (13, 25, 192)])
 @pytest.mark.parametrize("ydt", [torch.float32, torch.bfloat16])
 def test_layer_norm_patch_merge(ops, H, W, C, ydt):
@@ -857,6 +882,22 @@ def test_gemm_nt_against_torch(ops, M, K, N, tile_m, with_bias):
     assert y.shape == (M, N) and y.dtype == torch.bfloat16
     assert torch.allclose(y.float(), ref, rtol=1e-2, atol=1e-2), (y.float() - ref).abs().max()
     assert not ops.gemm_nt_supported(x, N + 64) and not ops.gemm_nt_supported(x[:, :K - 32].contiguous(), N)
+
+
+@pytest.mark.parametrize("M,K,N,tile_m", [(16384, 768, 384, 0), (65536, 384, 192, 128), (4096, 1536, 768, 64), (333, 192, 384, 0), (65, 128, 192, 64)])
+def test_gemm_nt_with_an_f32_result_is_the_unrounded_product(ops, M, K, N, tile_m):
+    """pswin_gemm_nt_f32 (PatchMerging.reduction -> the fp32 residual stream): the same accumulators as pswin_gemm_nt, stored
+    without the bf16 rounding -- its bf16 rounding IS pswin_gemm_nt's result, and it matches the fp32 matmul tightly."""
+    torch.manual_seed(M + K + N)
+    x = torch.randn(M, K, device=DEV).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=DEV) / math.sqrt(K)).to(torch.bfloat16)
+    b = torch.randn(N, device=DEV)
+    y32 = ops.gemm_nt(x, w, b, tile_m, out_f32=True)
+    y16 = ops.gemm_nt(x, w, b, tile_m)
+    assert y32.dtype == torch.float32 and y32.shape == (M, N)
+    assert torch.equal(y32.to(torch.bfloat16), y16)
+    ref = x.float() @ w.float().t() + b
+    assert torch.allclose(y32, ref, rtol=2e-4, atol=2e-4), (y32 - ref).abs().max()
 
 
 def test_linear_on_the_tiled_gemm_matches_the_library_path(ops):
