@@ -22,6 +22,8 @@
 //     stores;
 //   * tiles are dealt to the XCDs in contiguous chunks (blockIdx % 8 = XCD under round-robin placement; speed only) with
 //     the column tile fastest, so the tiles that share an activation panel hit the same L2.
+#include <cstdlib>
+
 #include "pswin_common.hpp"
 #include "pswin_gelu.hpp"
 
@@ -82,7 +84,12 @@ __device__ inline void glds16(const void* gsrc, char* lds_wave_base) {
 // bias + GELU backward pass (two reads and a write of [M, 4C]) is gone.  EPI 2 (fc1 + bias + nn.GELU forward): y = acc (the
 // pre-activation WITHOUT bias, kept for the backward pass) and, to the second output `aux`, h = gelu(bf16(acc) + bias) -- the
 // value the separate bias + GELU kernel computes from the stored pre-activation, bit for bit; the f32 bias comes in `partial`.
-template <int BM, int EPI>
+// S = LDS stages.  2: one k-step in flight under the current one, two workgroups per CU (the form every large launch runs).  4 (round 4):
+// three k-steps in flight, one workgroup per CU -- for launches whose tiles fit the chip once: there a workgroup has nobody to overlap
+// with, every k-step of the two-stage loop waits out a full (cold: HBM) load latency, and the launch takes ramp + K / 64 latencies
+// whatever its size.  The wait in front of a step is then a COUNTED vmcnt that leaves the younger stages' LDS-DMA outstanding and the
+// barrier a raw s_barrier (a __syncthreads() drains vmcnt to 0), as in pswin_gemm_tn.hip.
+template <int BM, int EPI, int S = 2>
 __global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_kernel(const unsigned short* __restrict__ X, const unsigned short* __restrict__ W,
                                                                  const float* __restrict__ bias, unsigned short* __restrict__ Y,
                                                                  int M, int N, int K, int tiles_m, int tiles_n,
@@ -92,7 +99,7 @@ __global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_kernel(const unsigned s
     constexpr int AJ = BM / 32, BJ = BN / 32;         // 8-row LDS-DMA blocks per wave and k-step (4 waves)
     constexpr int CT = BN / 32;                       // 16-column tiles per wave: 6
     constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
-    extern __shared__ __attribute__((aligned(1024))) char smem[];       // 2 stages: [A tile | B tile]
+    extern __shared__ __attribute__((aligned(1024))) char smem[];       // S stages: [A tile | B tile]
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int c = lane & 15, g = lane >> 4;
@@ -154,13 +161,34 @@ __global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_kernel(const unsigned s
     };
 
     const int KT = K / BK;
+    constexpr int LOADS = AJ + BJ;                    // LDS-DMA instructions per wave and k-step
+    static_assert(S == 2 || S == 4, "");
+    static_assert(2 * LOADS <= 63, "vmcnt");
     issue(0, 0);
+    if constexpr (S == 4) {
+        if (1 < KT) issue(1, 1);
+        if (2 < KT) issue(2, 2);
+    }
+    int stage = 0;
     for (int kt = 0; kt < KT; ++kt) {
-        __syncthreads();                              // (vmcnt(0) + barrier) stage kt landed for every wave; stage kt-1 fully consumed
-        if (kt + 1 < KT && PSWIN_NT_PROBE != 1) issue(kt + 1, (kt + 1) & 1);
+        if constexpr (S == 2) {
+            __syncthreads();                          // (vmcnt(0) + barrier) stage kt landed for every wave; stage kt-1 fully consumed
+            if (kt + 1 < KT && PSWIN_NT_PROBE != 1) issue(kt + 1, (kt + 1) & 1);
+            stage = kt & 1;
+        } else {
+            // this wave's loads of step kt have landed once only the younger steps' (at most two) are outstanding; the barrier says so for
+            // every wave and that every wave is done reading step kt - 1, whose stage the next issue overwrites
+            const int younger = KT - 1 - kt;
+            if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LOADS) : "memory");
+            else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(LOADS) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            stage = kt & 3;
+            if (kt + 3 < KT) issue(kt + 3, (kt + 3) & 3);
+        }
         if (PSWIN_NT_PROBE == 2) continue;
-        const char* sa = smem + (kt & 1) * STAGE + a_lane;
-        const char* sb = smem + (kt & 1) * STAGE + A_BYTES + b_lane;
+        const char* sa = smem + stage * STAGE + a_lane;
+        const char* sb = smem + stage * STAGE + A_BYTES + b_lane;
         // the fragments of the second 32-deep half are requested after the first four MFMAs of the first half and arrive under its
         // other twenty (two register sets): the wait in front of the first MFMA then covers the first set only
         u32x4 af[2][RT], bf[2][CT];
@@ -305,17 +333,31 @@ __global__ __launch_bounds__(NT_THREADS, 2) void gemm_nt_kernel(const unsigned s
     }
 }
 
-template <int BM, int EPI>
-int launch_nt(const void* x, const void* w, const float* bias, void* y, int M, int N, int K, hipStream_t st, const void* aux = nullptr,
-              float* partial = nullptr) {
-    constexpr size_t lds = 2 * (size_t)(BM + BN) * BK * 2;
+template <int BM, int EPI, int S>
+int launch_nt_s(const void* x, const void* w, const float* bias, void* y, int M, int N, int K, hipStream_t st, const void* aux, float* partial) {
+    constexpr size_t lds = S * (size_t)(BM + BN) * BK * 2;
+    static_assert(lds <= 160 * 1024, "LDS");
     static std::atomic<unsigned long long> configured{0};
-    if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, EPI>), lds, configured)) return rc;
+    if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&gemm_nt_kernel<BM, EPI, S>), lds, configured)) return rc;
     const int tiles_m = (M + BM - 1) / BM, tiles_n = N / BN;
-    hipLaunchKernelGGL((gemm_nt_kernel<BM, EPI>), dim3(tiles_m * tiles_n), dim3(NT_THREADS), lds, st,
+    hipLaunchKernelGGL((gemm_nt_kernel<BM, EPI, S>), dim3(tiles_m * tiles_n), dim3(NT_THREADS), lds, st,
                        reinterpret_cast<const unsigned short*>(x), reinterpret_cast<const unsigned short*>(w), bias,
                        reinterpret_cast<unsigned short*>(y), M, N, K, tiles_m, tiles_n, reinterpret_cast<const unsigned short*>(aux), partial);
     PSWIN_LAUNCH_RET();
+}
+
+// launches of at most this many tiles take the four-stage form (one workgroup per CU): PSWIN_GEMM_NT_DEEP_TILES overrides (0 = never)
+inline int deep_tiles() {
+    static const int v = getenv("PSWIN_GEMM_NT_DEEP_TILES") ? atoi(getenv("PSWIN_GEMM_NT_DEEP_TILES")) : 256;
+    return v;
+}
+
+template <int BM, int EPI>
+int launch_nt(const void* x, const void* w, const float* bias, void* y, int M, int N, int K, hipStream_t st, const void* aux = nullptr,
+              float* partial = nullptr) {
+    const int tiles = ((M + BM - 1) / BM) * (N / BN);
+    if (tiles <= deep_tiles() && K / BK >= 3) return launch_nt_s<BM, EPI, 4>(x, w, bias, y, M, N, K, st, aux, partial);
+    return launch_nt_s<BM, EPI, 2>(x, w, bias, y, M, N, K, st, aux, partial);
 }
 
 }  // namespace

@@ -768,14 +768,19 @@ def gemm_nt_supported(x2d, n_out):
 
 def gemm_nt_tile(M, K, N):
     """Row-tile height (64 / 128) with which pswin_gemm_nt computes [M, K] x [N, K]^T, or 0 = leave it to the library.
-    From profiles/r02_gemm_nt_vs_library.txt (MI355X, PanoSwin-T shapes at batch 8): the HIP kernel wins wherever the rows fill
-    the chip (M >= 8192: stages 1-2) and, for the 4-6 k rows of stage 3, on the narrow outputs with a short contraction;
-    128-row tiles once they give every CU two rounds of work."""
+    From profiles/r02_gemm_nt_vs_library.txt (MI355X, PanoSwin-T shapes at batch 8) and the in-step A/Bs of round 4
+    (profiles/r04_ab_runs.json: gemm_nt_*): the HIP kernel wins wherever the rows fill the chip (M >= 8192: stages 1-2), on the narrow
+    outputs with a short contraction at 4-6 k rows, and wherever 128-row tiles still give every CU two rounds of work (stage 3's qkv / fc1
+    at batch 8); 128-row tiles then, or when they make the launch fit the chip ONCE (<= 256 tiles: the kernel's four-stage form,
+    csrc/pswin_gemm_nt.hip) while 64-row tiles would not; 64-row tiles otherwise."""
     if not GEMM_NT or not bool(_lib.load().pswin_gemm_nt_supported(M, K, N)):
         return 0
-    if M < 8192 and not (N <= 768 and K <= 1536):
+    t64, t128 = -(-M // 64) * (N // 192), -(-M // 128) * (N // 192)
+    if M < 8192 and not (N <= 768 and K <= 1536) and t128 < 512:
         return 0
-    return 128 if -(-M // 128) * (N // 192) >= 512 else 64
+    if t128 < 512 and t64 > 256 and t128 <= 256:
+        return 128
+    return 128 if t128 >= 512 else 64
 
 
 def transpose_weights(pairs):
