@@ -100,6 +100,10 @@ def _launch_reductions(jobs):
         call("pswin_reduce_jobs", lst[0][0], ctypes.cast(arr, ctypes.c_void_p), len(lst))
 
 
+# PSWIN_DEFER_TABLE_PARTIALS=0: the dScore-tile sums of an attention module run inside its backward (A/B)
+DEFER_TABLE_PARTIALS = os.environ.get("PSWIN_DEFER_TABLE_PARTIALS", "1") != "0"
+
+
 def _launch_table_grads(jobs, stages=3):
     import ctypes
     by_dev = {}
@@ -140,6 +144,8 @@ def _launch_queue(q):
     q["jobs"], q["table_jobs"], q["wgrad_jobs"] = [], [], []
     if wjobs:
         _launch_wgrads(wjobs)                           # the reductions below sum their partial slabs
+    if tjobs and DEFER_TABLE_PARTIALS:
+        _launch_table_grads(tjobs, 1)                   # partial-row sums of every attention module's dScore tiles, one launch
     if jobs:
         _launch_reductions(jobs)
     if tjobs:
@@ -1527,13 +1533,15 @@ def attention_backward(x, k, v, lse, alpha, beta, dist, mask, dout, heads, scale
         ws = torch.empty(lib.pswin_attn_table_grads_workspace(heads), dtype=torch.float32, device=x.device)
         job = (gsum, None if dist is None else dist.bwd, dalpha, dbeta, ws, chunks * nb, nb,
                0 if dist is None else dist.n, heads)
-        # the sum over the dScore tiles runs now (they are still in the last-level cache); with deferred reductions
-        # the sum of its partial rows joins the grouped launch at the end of the pass and ONE binning launch serves
-        # all attention modules (same kernels, same order either way: bitwise equal results)
-        _launch_table_grads([job], 1)
+        # with deferred reductions the whole table gradient waits for the end of the pass: ONE launch sums the dScore tiles of all
+        # attention modules (round 4: twelve launches of 9-15 us per step were mostly ramp; the tiles -- 16 KB per work item and head,
+        # ~190 MB per PanoSwin-T step at batch 8 -- stay referenced by the queue until then), the sum of its partial rows joins the grouped
+        # reduction and ONE binning launch follows (same kernels, same per-module decomposition either way: bitwise equal results)
         ld = ws.numel() // 129
         rjob = (ws, 0, F32, lib.pswin_attn_table_grads_partial_rows(chunks * nb, heads), ld, ld, ws[128 * ld:])
         q = _deferring(owners)
+        if q is None or not DEFER_TABLE_PARTIALS:
+            _launch_table_grads([job], 1)
         if q is not None:
             q["jobs"].append(rjob)
             q["table_jobs"].append(job)
