@@ -289,6 +289,15 @@ def main():
             reducer.finish()
             g_opt()
             return loss
+    elif world == 1:
+        # one process, nothing to exchange between the backward pass and the update: the whole step is ONE hipGraph
+        from panoswintransformerobjectdetection_amd.graph import GraphedCallable
+
+        def fwd_bwd_update():
+            loss = fwd_bwd()
+            opt.step()
+            return loss
+        step = GraphedCallable(fwd_bwd_update, warmup=2, stream=cap_stream)
     else:
         # One hipGraph for forward+backward, one for the optimizer; the RCCL all-reduce of the flat gradient buffer
         # runs between the two replays (N > 1), so collectives are never part of a captured graph.
