@@ -781,9 +781,15 @@ def gemm_nt_tile(M, K, N):
     csrc/pswin_gemm_nt.hip) while 64-row tiles would not; 64-row tiles otherwise."""
     if not GEMM_NT or not bool(_lib.load().pswin_gemm_nt_supported(M, K, N)):
         return 0
-    t64, t128 = -(-M // 64) * (N // 192), -(-M // 128) * (N // 192)
+    t128 = -(-M // 128) * (N // 192)
     if M < 8192 and not (N <= 768 and K <= 1536) and t128 < 512:
         return 0
+    return gemm_nt_rows(M, N)
+
+
+def gemm_nt_rows(M, N):
+    """the row-tile height for a product that runs on pswin_gemm_nt in any case (the fused GELU forms have no library counterpart)"""
+    t64, t128 = -(-M // 64) * (N // 192), -(-M // 128) * (N // 192)
     if t128 < 512 and t64 > 256 and t128 <= 256:
         return 128
     return 128 if t128 >= 512 else 64
@@ -1262,7 +1268,7 @@ class _BiasGeluLinear(torch.autograd.Function):
         lib = _lib.load()
         tile = 0
         if wbt is not None and GEMM_NT and lib.pswin_gemm_nt_supported(M, C, N):
-            tile = gemm_nt_tile(M, C, N) or 64        # (the narrow stage-3 case the plain rule leaves to the library: fused it wins)
+            tile = gemm_nt_tile(M, C, N) or gemm_nt_rows(M, N)        # (the narrow stage-3 case the plain rule leaves to the library: fused it wins)
         if tile:
             dpre = torch.empty_like(y2)
             rows = lib.pswin_gemm_nt_partial_rows(M, tile)
@@ -1298,7 +1304,7 @@ class _MlpFused(torch.autograd.Function):
         b = b1.detach().float().contiguous()
         pre = torch.empty(M, N, dtype=x.dtype, device=x.device)
         h = torch.empty_like(pre)
-        call("pswin_gemm_nt_gelu_fwd", x, ptr(x), ptr(w1b), ptr(b), ptr(pre), ptr(h), M, K, N, gemm_nt_tile(M, K, N) or 64,
+        call("pswin_gemm_nt_gelu_fwd", x, ptr(x), ptr(w1b), ptr(b), ptr(pre), ptr(h), M, K, N, gemm_nt_tile(M, K, N) or gemm_nt_rows(M, N),
              algo_bytes=2 * (M * K + 2 * M * N + N * K), algo_flops=2 * M * K * N)
         tile = gemm_nt_tile(M, N, C)
         if tile:
@@ -1319,7 +1325,7 @@ class _MlpFused(torch.autograd.Function):
         dout = dout.contiguous()
         lib = _lib.load()
         if w2bt is not None:
-            tile = gemm_nt_tile(M, C, N) or 64
+            tile = gemm_nt_tile(M, C, N) or gemm_nt_rows(M, N)
             dpre = torch.empty_like(pre)
             rows = lib.pswin_gemm_nt_partial_rows(M, tile)
             ws = torch.empty(rows, N, dtype=torch.float32, device=pre.device)
