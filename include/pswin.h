@@ -318,9 +318,10 @@ int pswin_stem_conv1_wgrad(const float* out5, const float* xx, const void* w1p, 
 
 /* Tiled bf16 GEMM for the Linear layers of stages 1-3 (qkv / proj / fc1 / fc2 / reduction, HOT:287, 309, 50-58, 575) and,
  * through a transposed copy of the weight, their data gradients:  y[M, N] = x[M, K] . w[N, K]^T (+ bias), bf16 in / out,
- * f32 accumulation, bias f32 [N] or NULL.  128 (or 64) x 192 macro tiles, both operands by LDS-DMA into XOR-swizzled
- * double-buffered LDS tiles (csrc/pswin_gemm_nt.hip).  Needs N % 192 == 0, K % 64 == 0, M >= 64 (pswin_gemm_nt_supported).
- * tile_m: 0 = choose, or 64 / 128. */
+ * f32 accumulation, bias f32 [N] or NULL.  128 (or 64 / 96) x 192 macro tiles, both operands by LDS-DMA into XOR-swizzled
+ * LDS tiles: double buffered with two workgroups per CU, or -- launches of at most 256 tiles -- four stages with three k-steps in
+ * flight and one workgroup per CU (csrc/pswin_gemm_nt.hip).  Needs N % 192 == 0, K % 64 == 0, M >= 64 (pswin_gemm_nt_supported).
+ * tile_m: 0 = choose, or 64 / 96 / 128 (96: plain epilogue only). */
 /* The same product with a three-stage LDS ring (counted waits, one raw barrier per 64-row slab, one 8-wave workgroup per CU):
  * csrc/pswin_gemm_tn.hip, "Round 3".  One macro tile of 192 x 192 serves every Linear of the model (N % 192 == 0, K % 192 == 0).
  * partial: [splits, N, K] in `partial_dtype` (PSWIN_F32, or PSWIN_BF16 = each split's tile rounded once, as the library's batched GEMM

@@ -368,13 +368,15 @@ int pswin_gemm_nt_supported(long long M, int K, int N) {
     return M >= 64 && M * (long long)(K > N ? K : N) * 2 < 0xFFFFFF00ll && K >= 64 && K % 64 == 0 && N >= 192 && N % 192 == 0;
 }
 
-/* tile_m: 0 = choose (128-row tiles unless that leaves the 256 CUs short of two rounds of tiles), or 64 / 128 */
+/* tile_m: 0 = choose (128-row tiles unless that leaves the 256 CUs short of two rounds of tiles), or 64 / 96 / 128 */
 int pswin_gemm_nt(const void* x, const void* w, const float* bias, void* y, long long M, int K, int N, int tile_m, void* stream) {
-    PSWIN_CHECK_ARG(x && w && y && pswin_gemm_nt_supported(M, K, N) && (tile_m == 0 || tile_m == 64 || tile_m == 128));
+    PSWIN_CHECK_ARG(x && w && y && pswin_gemm_nt_supported(M, K, N) && (tile_m == 0 || tile_m == 64 || tile_m == 96 || tile_m == 128));
     PSWIN_CHECK_ARG(aligned16(x) && aligned16(w) && aligned16(y) && aligned16(bias));
     const int m = (int)M;
     if (tile_m == 0) tile_m = ((long long)((m + 127) / 128) * (N / BN) >= 512) ? 128 : 64;
     if (tile_m == 128) return launch_nt<128, 0>(x, w, bias, y, m, N, K, (hipStream_t)stream);
+    // 96-row tiles (plain epilogue only): for row counts whose 64-row tiles need a second, mostly empty round of the 512 tile slots
+    if (tile_m == 96) return launch_nt<96, 0>(x, w, bias, y, m, N, K, (hipStream_t)stream);
     return launch_nt<64, 0>(x, w, bias, y, m, N, K, (hipStream_t)stream);
 }
 

@@ -772,6 +772,9 @@ def gemm_nt_supported(x2d, n_out):
             and bool(_lib.load().pswin_gemm_nt_supported(x2d.shape[0], x2d.shape[1], n_out)))
 
 
+GEMM_NT_96 = os.environ.get("PSWIN_GEMM_NT_96", "1") != "0"
+
+
 def gemm_nt_tile(M, K, N):
     """Row-tile height (64 / 128) with which pswin_gemm_nt computes [M, K] x [N, K]^T, or 0 = leave it to the library.
     From profiles/r02_gemm_nt_vs_library.txt (MI355X, PanoSwin-T shapes at batch 8) and the in-step A/Bs of round 4
@@ -784,7 +787,13 @@ def gemm_nt_tile(M, K, N):
     t128 = -(-M // 128) * (N // 192)
     if M < 8192 and not (N <= 768 and K <= 1536) and t128 < 512:
         return 0
-    return gemm_nt_rows(M, N)
+    rows = gemm_nt_rows(M, N)
+    if GEMM_NT_96 and rows == 64:
+        # 64-row tiles that spill into a second, mostly empty round of the 512 tile slots (two workgroups per CU): 96-row tiles in one
+        t64, t96 = -(-M // 64) * (N // 192), -(-M // 96) * (N // 192)
+        if 512 < t64 <= 768 and t96 <= 512:
+            return 96
+    return rows
 
 
 def gemm_nt_rows(M, N):

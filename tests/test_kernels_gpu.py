@@ -865,7 +865,8 @@ def test_fused_window_attention_rejects_what_it_is_not_built_for(ops):
 
 
 @pytest.mark.parametrize("M,K,N,tile_m", [(19600, 384, 1152, 0), (16384, 384, 1536, 128), (4096, 3072, 768, 64), (5880, 768, 2304, 0),
-                                          (200, 64, 192, 64), (333, 192, 384, 128), (74480, 192, 576, 0), (65, 128, 192, 0)])
+                                          (200, 64, 192, 64), (333, 192, 384, 128), (74480, 192, 576, 0), (65, 128, 192, 0),
+                                          (19600, 1152, 384, 96), (19600, 384, 384, 96), (100, 192, 192, 96), (5880, 768, 768, 96)])
 @pytest.mark.parametrize("with_bias", [False, True])
 def test_gemm_nt_against_torch(ops, M, K, N, tile_m, with_bias):
     """pswin_gemm_nt (LDS-DMA tiles, swizzled LDS, transposed-product epilogue) against an fp32 matmul of the same bf16
