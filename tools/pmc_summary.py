@@ -20,9 +20,11 @@ KERNELS = {"win_fused_fwd_kernel": "pswin_win_attn_fused_fwd", "attn_fwd_kernel"
            "window_scatter_add_kernel": "pswin_window_scatter_add", "window_scatter_add8_kernel": "pswin_window_scatter_add",
            "ln_add_fwd_kernel": "pswin_scatter_add_ln_fwd",
            # the tiled GEMM by epilogue (template arguments <rows, EPI>): plain, fused GELU backward, fused GELU forward
-           "gemm_nt_kernel<64, 0>": "pswin_gemm_nt", "gemm_nt_kernel<128, 0>": "pswin_gemm_nt",
-           "gemm_nt_kernel<64, 1>": "pswin_gemm_nt_gelu_bwd", "gemm_nt_kernel<128, 1>": "pswin_gemm_nt_gelu_bwd",
-           "gemm_nt_kernel<64, 2>": "pswin_gemm_nt_gelu_fwd", "gemm_nt_kernel<128, 2>": "pswin_gemm_nt_gelu_fwd",
+           # (round 4: a third template argument = LDS stages; 96-row tiles; EPI 3 = f32 result)
+           "gemm_nt_kernel<64, 0,": "pswin_gemm_nt", "gemm_nt_kernel<96, 0,": "pswin_gemm_nt", "gemm_nt_kernel<128, 0,": "pswin_gemm_nt",
+           "gemm_nt_kernel<64, 3,": "pswin_gemm_nt", "gemm_nt_kernel<128, 3,": "pswin_gemm_nt",
+           "gemm_nt_kernel<64, 1,": "pswin_gemm_nt_gelu_bwd", "gemm_nt_kernel<128, 1,": "pswin_gemm_nt_gelu_bwd",
+           "gemm_nt_kernel<64, 2,": "pswin_gemm_nt_gelu_fwd", "gemm_nt_kernel<128, 2,": "pswin_gemm_nt_gelu_fwd",
            # round 3
            "gemm_tn_ring_kernel": "pswin_gemm_tn_ring", "qkv_attn_fwd_kernel": "pswin_qkv_attn_fused_fwd", "mlp0_fwd_kernel": "pswin_mlp0_fwd",
            "mlp0_bwd_kernel": "pswin_mlp0_bwd", "skinny_gemm_kernel": "pswin_gemm_skinny"}
