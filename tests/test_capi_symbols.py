@@ -50,7 +50,7 @@ def test_argument_errors_of_the_round_2_entry_points_without_a_gpu():
     assert lib.pswin_gemm_nt_supported(16384, 384, 1536) == 1 and lib.pswin_gemm_nt_supported(16384, 384, 1500) == 0
     assert lib.pswin_gemm_nt_supported(32, 384, 1536) == 0 and lib.pswin_gemm_nt_supported(16384, 100, 1536) == 0
     assert lib.pswin_gemm_nt(None, p16, None, p16, 16384, 384, 1536, 0, None) == ERR                      # null operand
-    assert lib.pswin_gemm_nt(p16, p16, None, p16, 16384, 384, 1536, 96, None) == ERR                      # tile height
+    assert lib.pswin_gemm_nt(p16, p16, None, p16, 16384, 384, 1536, 80, None) == ERR                      # tile height (64, 96, 128)
     assert lib.pswin_gemm_nt(p16 + 2, p16, None, p16, 16384, 384, 1536, 0, None) == ERR                   # alignment
     assert lib.pswin_gemm_nt_gelu_fwd(p16, p16, None, p16, p16, 16384, 384, 1536, 128, None) == ERR       # fc1 bias is required
     assert lib.pswin_gemm_nt_gelu_fwd(p16, p16, p16, p16, p16, 16384, 384, 1536, 0, None) == ERR          # explicit tile height
