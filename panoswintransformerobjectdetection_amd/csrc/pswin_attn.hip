@@ -913,10 +913,7 @@ __global__ __launch_bounds__(256) void dtab_final_kernel(const TBatch b) {
 // PanoSwin-T stage shapes on MI355X (tools/bench_attn.py): forward (2 waves/SIMD) ~1100 items, backward
 // (1 wave/SIMD, heavier items) ~600 items.
 inline int pick_chunks(int reps, int nb, int heads, bool backward) {
-    // PSWIN_ATTN_TARGET_FWD / _BWD: tuning override for sweeps inside the full step (tools/ab_attn_chunks.sh)
-    static const long long tf = getenv("PSWIN_ATTN_TARGET_FWD") ? atoll(getenv("PSWIN_ATTN_TARGET_FWD")) : 1100;
-    static const long long tb = getenv("PSWIN_ATTN_TARGET_BWD") ? atoll(getenv("PSWIN_ATTN_TARGET_BWD")) : 600;
-    const long long target = backward ? tb : tf;
+    const long long target = backward ? 600 : 1100;          // swept inside the full step in round 2 (profiles/r02_*)
     int best = reps;
     for (int ch = 1; ch <= reps; ++ch) {
         if (reps % ch) continue;

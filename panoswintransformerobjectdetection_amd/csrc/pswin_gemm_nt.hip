@@ -22,8 +22,6 @@
 //     stores;
 //   * tiles are dealt to the XCDs in contiguous chunks (blockIdx % 8 = XCD under round-robin placement; speed only) with
 //     the column tile fastest, so the tiles that share an activation panel hit the same L2.
-#include <cstdlib>
-
 #include "pswin_common.hpp"
 #include "pswin_gelu.hpp"
 
@@ -346,17 +344,15 @@ int launch_nt_s(const void* x, const void* w, const float* bias, void* y, int M,
     PSWIN_LAUNCH_RET();
 }
 
-// launches of at most this many tiles take the four-stage form (one workgroup per CU): PSWIN_GEMM_NT_DEEP_TILES overrides (0 = never)
-inline int deep_tiles() {
-    static const int v = getenv("PSWIN_GEMM_NT_DEEP_TILES") ? atoi(getenv("PSWIN_GEMM_NT_DEEP_TILES")) : 256;
-    return v;
-}
+// launches of at most this many tiles take the four-stage form (one workgroup per CU); swept 0 / 256 / 512 / 1024 inside the step
+// (profiles/r04_ab_runs.json: gemm_nt_four_stage_threshold_tiles)
+constexpr int DEEP_TILES = 256;
 
 template <int BM, int EPI>
 int launch_nt(const void* x, const void* w, const float* bias, void* y, int M, int N, int K, hipStream_t st, const void* aux = nullptr,
               float* partial = nullptr) {
     const int tiles = ((M + BM - 1) / BM) * (N / BN);
-    if (tiles <= deep_tiles() && K / BK >= 3) return launch_nt_s<BM, EPI, 4>(x, w, bias, y, M, N, K, st, aux, partial);
+    if (tiles <= DEEP_TILES && K / BK >= 3) return launch_nt_s<BM, EPI, 4>(x, w, bias, y, M, N, K, st, aux, partial);
     return launch_nt_s<BM, EPI, 2>(x, w, bias, y, M, N, K, st, aux, partial);
 }
 

@@ -20,7 +20,6 @@
 //     packed [49][32] blocks and the log-sum-exp rows for pswin_attn_bwd_ex.
 // Rounding points are those of the unfused bf16 path: q, k, v and the attention output are rounded to bf16 before they are used as
 // operands / stored; scores, softmax and all accumulation are f32.
-#include <cstdlib>
 
 #include "pswin_attn_frag.hpp"
 
@@ -466,8 +465,6 @@ int launch_qkv_attn(QkvAttnArgs a, hipStream_t st) {
         while (rp < a.reps) rp *= 2;
         group = QWAVES / rp;
         if (group > G::GROUP_MAX) group = G::GROUP_MAX;
-        static const int cap = [] { const char* e = getenv("PSWIN_QKV_ATTN_GROUP_MAX"); return e ? atoi(e) : 8; }();     // (A/B: 1 = the round-3 wave assignment)
-        if (group > cap) group = cap < 1 ? 1 : cap;
     }
     a.group = group;
 #ifdef PSWIN_QA_PROBE

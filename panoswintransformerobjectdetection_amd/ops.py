@@ -14,16 +14,25 @@ from . import _lib
 from ._lib import BF16, F32, MODE_PANO, MODE_PLANAR, WPAD, WTOK, PswinError, call, dtype_code, ptr
 
 _CACHE = {}
-# the per-window qkv -> attention -> proj kernel where it exists (C = 96); PSWIN_FUSED_ATTN=0 selects the unfused chain (A/B)
-FUSED_WINDOW_ATTENTION = os.environ.get("PSWIN_FUSED_ATTN", "1") != "0"
+# Feature switches.  Every one of them selects between two HIP paths (a fused kernel or the chain of kernels it replaces), never a CPU
+# path; tests flip the module attributes to compare the two.  ONE environment variable remains for same-box A/B runs of the whole step:
+# PSWIN_DISABLE="name[,name...]" turns the named features off (names = the lower-case attribute names below).
+_DISABLED = {n.strip().lower() for n in os.environ.get("PSWIN_DISABLE", "").split(",") if n.strip()}
+
+
+def _on(name):
+    return name not in _DISABLED
+
+
+# the per-window qkv -> attention -> proj kernel where it exists (C = 96); off: the unfused chain
+FUSED_WINDOW_ATTENTION = _on("fused_window_attention")
 # the tiled HIP GEMM (pswin_gemm_nt) for the Linear layers of stages 1-3 where it measured faster than the library kernels
-# (profiles/r02_gemm_nt_vs_library.txt); PSWIN_GEMM_NT=0: library GEMMs everywhere (A/B)
-GEMM_NT = os.environ.get("PSWIN_GEMM_NT", "1") != "0"
-# fc2's data gradient + the backward of fc1's bias + GELU in one kernel (pswin_gemm_nt_gelu_bwd); PSWIN_FUSED_GELU_BWD=0: two kernels
-FUSED_GELU_BWD = os.environ.get("PSWIN_FUSED_GELU_BWD", "1") != "0"
-# fc1 with the bias + GELU in its epilogue (pswin_gemm_nt_gelu_fwd) and fc2 as one autograd node; PSWIN_FUSED_MLP=0: GEMM, then a
-# streaming bias + GELU pass
-FUSED_MLP = os.environ.get("PSWIN_FUSED_MLP", "1") != "0"
+# (profiles/r02_gemm_nt_vs_library.txt, profiles/r04_ab_runs.json); off: library GEMMs for those layers
+GEMM_NT = _on("gemm_nt")
+# fc2's data gradient + the backward of fc1's bias + GELU in one kernel (pswin_gemm_nt_gelu_bwd); off: two kernels
+FUSED_GELU_BWD = _on("fused_gelu_bwd")
+# fc1 with the bias + GELU in its epilogue (pswin_gemm_nt_gelu_fwd) and fc2 as one autograd node; off: GEMM, then a streaming bias + GELU pass
+FUSED_MLP = _on("fused_mlp")
 
 
 def _dev_key(device):
@@ -100,8 +109,8 @@ def _launch_reductions(jobs):
         call("pswin_reduce_jobs", lst[0][0], ctypes.cast(arr, ctypes.c_void_p), len(lst))
 
 
-# PSWIN_DEFER_TABLE_PARTIALS=0: the dScore-tile sums of an attention module run inside its backward (A/B)
-DEFER_TABLE_PARTIALS = os.environ.get("PSWIN_DEFER_TABLE_PARTIALS", "1") != "0"
+# off: the dScore-tile sums of an attention module run inside its backward instead of in one launch at the end of the pass
+DEFER_TABLE_PARTIALS = _on("defer_table_partials")
 
 
 def _launch_table_grads(jobs, stages=3):
@@ -516,14 +525,14 @@ def layer_norm_gather(x, gamma, beta, eps, wmap=None, inv=None, out_dtype=None, 
 
 
 # the window gather (or bf16 cast) of window_scatter_add's backward from inside the LayerNorm backward kernel (pswin_ln_gather_bwd_ex) and
-# the next block's norm1 + partition from inside the residual add (pswin_scatter_add_ln_fwd_map); PSWIN_LN_FUSED_MOVES=0: separate kernels (A/B)
-LN_FUSED_MOVES = os.environ.get("PSWIN_LN_FUSED_MOVES", "1") != "0"
+# the next block's norm1 + partition from inside the residual add (pswin_scatter_add_ln_fwd_map); off: separate kernels
+LN_FUSED_MOVES = _on("ln_fused_moves")
 
 
 class _ScatterAddLayerNorm(torch.autograd.Function):
     """window_scatter_add + LayerNorm in one forward pass (pswin_scatter_add_ln_fwd[_map]); the backward pass is the LayerNorm backward
     kernel (with the shortcut gradient folded in, as layer_norm_gather(passthrough=True)) which also writes the window gather of
-    window_scatter_add's backward (pswin_ln_gather_bwd_ex) -- or, with PSWIN_LN_FUSED_MOVES=0 / fp32 windows, followed by that gather."""
+    window_scatter_add's backward (pswin_ln_gather_bwd_ex) -- or, with ln_fused_moves off / fp32 windows, followed by that gather."""
 
     @staticmethod
     def forward(ctx, win, resid, wmap, inv, scale, bias, gamma, beta, eps, out_dtype, res_bias, res_scale, in_pads, out_inv, out_n, out_pads):
@@ -772,9 +781,6 @@ def gemm_nt_supported(x2d, n_out):
             and bool(_lib.load().pswin_gemm_nt_supported(x2d.shape[0], x2d.shape[1], n_out)))
 
 
-GEMM_NT_96 = os.environ.get("PSWIN_GEMM_NT_96", "1") != "0"
-
-
 def gemm_nt_tile(M, K, N):
     """Row-tile height (64 / 128) with which pswin_gemm_nt computes [M, K] x [N, K]^T, or 0 = leave it to the library.
     From profiles/r02_gemm_nt_vs_library.txt (MI355X, PanoSwin-T shapes at batch 8) and the in-step A/Bs of round 4
@@ -788,7 +794,7 @@ def gemm_nt_tile(M, K, N):
     if M < 8192 and not (N <= 768 and K <= 1536) and t128 < 512:
         return 0
     rows = gemm_nt_rows(M, N)
-    if GEMM_NT_96 and rows == 64:
+    if rows == 64:
         # 64-row tiles that spill into a second, mostly empty round of the 512 tile slots (two workgroups per CU): 96-row tiles in one
         t64, t96 = -(-M // 64) * (N // 192), -(-M // 96) * (N // 192)
         if 512 < t64 <= 768 and t96 <= 512:
@@ -817,20 +823,19 @@ def transpose_weights(pairs):
     call("pswin_transpose_jobs", pairs[0][0], ctypes.cast(arr, ctypes.c_void_p), len(pairs))
 
 
-# the three-stage ring kernel for weight gradients (pswin_gemm_tn_ring, round 3); PSWIN_GEMM_TN_RING=0: library batched GEMMs (A/B)
-GEMM_TN_RING = os.environ.get("PSWIN_GEMM_TN_RING", "1") != "0"
-# partial slabs of the row splits in bf16 (what the library's batched GEMM writes; half the slab traffic) or f32
-GEMM_TN_RING_BF16 = os.environ.get("PSWIN_GEMM_TN_RING_BF16", "1") != "0"
-GEMM_TN_RING_WGS = int(os.environ.get("PSWIN_GEMM_TN_RING_WGS", "0"))
-# the Linear's bias gradient (column sums of dy) from the weight-gradient launch instead of a pass of its own; 0: pswin_colsum (A/B)
-GEMM_TN_RING_BIAS = os.environ.get("PSWIN_GEMM_TN_RING_BIAS", "1") != "0"
+# the three-stage ring kernel for weight gradients (pswin_gemm_tn_ring, round 3); off: library batched GEMMs
+GEMM_TN_RING = _on("gemm_tn_ring")
+# partial slabs of the row splits in bf16 (what the library's batched GEMM writes; half the slab traffic), f32 for a single split
+GEMM_TN_RING_BF16 = True
+# the Linear's bias gradient (column sums of dy) from the weight-gradient launch instead of a pass of its own; off: pswin_colsum
+GEMM_TN_RING_BIAS = _on("gemm_tn_ring_bias")
 
 
 # Weight gradients held back to the end of the backward pass and issued as one launch per tile geometry (pswin_gemm_tn_ring_jobs) when
 # the parameter-gradient reductions are deferred too (set_deferred_reductions): a workgroup then contracts GROUPED_WGRAD_ROWS rows
-# instead of M / (256 / tiles).  PSWIN_GROUPED_WGRAD=0: one launch per weight gradient, where autograd produces it (A/B)
-GROUPED_WGRAD = os.environ.get("PSWIN_GROUPED_WGRAD", "1") != "0"
-GROUPED_WGRAD_ROWS = int(os.environ.get("PSWIN_GROUPED_WGRAD_ROWS", "2048"))
+# instead of M / (256 / tiles).  off: one launch per weight gradient, where autograd produces it
+GROUPED_WGRAD = _on("grouped_wgrad")
+GROUPED_WGRAD_ROWS = 2048                 # swept 1,024 / 2,048 / 4,096: profiles/r04_ab_runs.json
 
 
 def grouped_wgrad_splits(M):
@@ -880,13 +885,13 @@ def queue_weight_gradient(dy, x, weight, bias, zero_cols):
 def gemm_tn_ring_splits(M, N, K):
     """Row splits for pswin_gemm_tn_ring on dy [M, N], x [M, K], or 0 = not for this shape.  ONE rule per configuration, whether the
     product is launched alone or inside the grouped launch (the two modes then run the same arithmetic: the deferred step stays bit-equal
-    to the immediate one): about GROUPED_WGRAD_ROWS rows per workgroup by default; with PSWIN_GROUPED_WGRAD=0 the round-3 rule, one
+    to the immediate one): about GROUPED_WGRAD_ROWS rows per workgroup by default; with grouped_wgrad disabled the round-3 rule, one
     workgroup per CU and launch."""
     if not GEMM_TN_RING or M < 512 or not bool(_lib.load().pswin_gemm_tn_ring_supported(M, N, K)):
         return 0
     if GROUPED_WGRAD:
         return grouped_wgrad_splits(M)
-    return int(_lib.load().pswin_gemm_tn_ring_splits(M, N, K, GEMM_TN_RING_WGS))
+    return int(_lib.load().pswin_gemm_tn_ring_splits(M, N, K, 0))
 
 
 def gemm_tn_ring(dy, x, splits, out_dtype=torch.float32, bias_sums=False, zero_cols=None):
@@ -1176,10 +1181,10 @@ class _Mlp0(torch.autograd.Function):
         return dx, dw1, db1, dw2, None, None
 
 
-# PSWIN_MLP0_FUSED=0: the stage-0 Mlp as fc1 + GELU node and fc2 node (library data gradient, pswin_fc1_gelu_bwd) -- A/B
-MLP0_FUSED = os.environ.get("PSWIN_MLP0_FUSED", "1") != "0"
-# PSWIN_MLP0_FUSED_FWD=0: its forward as pswin_fc1_gelu_fwd + the streaming GEMM for fc2 -- A/B
-MLP0_FUSED_FWD = os.environ.get("PSWIN_MLP0_FUSED_FWD", "1") != "0"
+# off: the stage-0 Mlp as fc1 + GELU node and fc2 node (pswin_fc1_gelu_bwd)
+MLP0_FUSED = _on("mlp0_fused")
+# off: its forward as pswin_fc1_gelu_fwd + the streaming GEMM for fc2
+MLP0_FUSED_FWD = _on("mlp0_fused_fwd")
 
 
 def mlp0_fused_shape_ok(M, C, hidden):
@@ -1745,8 +1750,8 @@ def nms_groups(box_list, iou_thr):
 # ------------------------------------------------------------------------------------------------
 # qkv Linear + attention core in one kernel for C = 192 / 384 (pswin_qkv_attn_fused_fwd, round 3)
 # ------------------------------------------------------------------------------------------------
-# PSWIN_FUSED_QKV_ATTN=0: the unfused chain qkv GEMM -> pswin_attn_fwd (A/B)
-FUSED_QKV_ATTENTION = os.environ.get("PSWIN_FUSED_QKV_ATTN", "1") != "0"
+# off: the unfused chain qkv GEMM -> pswin_attn_fwd
+FUSED_QKV_ATTENTION = _on("fused_qkv_attention")
 
 
 class _WindowAttentionQkvFused(torch.autograd.Function):
