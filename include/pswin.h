@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define PSWIN_ABI_VERSION 1
+#define PSWIN_ABI_VERSION 2
 
 #define PSWIN_F32 0
 #define PSWIN_BF16 1
@@ -311,7 +311,8 @@ int pswin_stem_pack_weights(const float* w1, const float* w2, const float* w3, v
                             void* w3t, void* stream);
 int pswin_stem_bn_fold(const float* sum, const float* sumsq, double count, const float* gamma, const float* beta,
                        const float* conv_bias, float eps, float momentum, int training, float* running_mean,
-                       float* running_var, int C, float* prm, void* stream);
+                       float* running_var, int C, float* prm, long long* num_batches_tracked, void* stream);
+/* (num_batches_tracked: nn.BatchNorm2d's int64 counter, incremented by one on the device, or NULL) */
 int pswin_stem_bn2_coefs(const float* sums, const float* prm, double count, int training, float* prm5, void* stream);
 int pswin_stem_conv1_wgrad(const float* out5, const float* xx, const void* w1p, const float* prm1, double count, int training,
                            float* dw1, float* db1, void* stream);

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get("PSWIN_LIB") or os.path.join(_PKG, "libpswin_hip.so") 
 F32, BF16 = 0, 1
 MODE_PLANAR, MODE_PANO = 0, 1
 WS, WTOK, WPAD, HEAD_DIM = 7, 49, 64, 32
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 _ip = ctypes.POINTER(ctypes.c_int)
@@ -57,7 +57,7 @@ _PROTOTYPES = {
     "pswin_stem_conv2_wgrad": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp],
     "pswin_stem_conv2_bwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
     "pswin_stem_pack_weights": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
-    "pswin_stem_bn_fold": [_vp, _vp, ctypes.c_double, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _i, _vp, _vp],
+    "pswin_stem_bn_fold": [_vp, _vp, ctypes.c_double, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _i, _vp, _vp, _vp],
     "pswin_stem_bn2_coefs": [_vp, _vp, ctypes.c_double, _i, _vp, _vp],
     "pswin_stem_conv1_wgrad": [_vp, _vp, _vp, _vp, ctypes.c_double, _i, _vp, _vp, _vp],
     "pswin_gemm_tn_ring_supported": [ctypes.c_longlong, _i, _i],

@@ -621,9 +621,10 @@ __global__ void stem_bn_fold_kernel(const float* __restrict__ sum, const float* 
                                     const float* __restrict__ gamma, const float* __restrict__ beta,
                                     const float* __restrict__ conv_bias, float eps, float momentum, int training,
                                     float* __restrict__ running_mean, float* __restrict__ running_var, int C,
-                                    float* __restrict__ prm) {
+                                    float* __restrict__ prm, long long* __restrict__ num_batches_tracked) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
+    if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;       // nn.BatchNorm2d's counter (one launch less per BatchNorm and step)
     const float cb = conv_bias ? conv_bias[c] : 0.f;
     float mean, var;
     if (training) {
@@ -883,11 +884,11 @@ int pswin_stem_pack_weights(const float* w1, const float* w2, const float* w3, v
 
 int pswin_stem_bn_fold(const float* sum, const float* sumsq, double count, const float* gamma, const float* beta,
                        const float* conv_bias, float eps, float momentum, int training, float* running_mean,
-                       float* running_var, int C, float* prm, void* stream) {
+                       float* running_var, int C, float* prm, long long* num_batches_tracked, void* stream) {
     PSWIN_CHECK_ARG(gamma && beta && prm && C > 0 && C <= 1024 && count > 0);
     PSWIN_CHECK_ARG(training ? (sum && sumsq) : (running_mean && running_var));
     hipLaunchKernelGGL(stem_bn_fold_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, sum, sumsq, count, gamma,
-                       beta, conv_bias, eps, momentum, training, running_mean, running_var, C, prm);
+                       beta, conv_bias, eps, momentum, training, running_mean, running_var, C, prm, num_batches_tracked);
     PSWIN_LAUNCH_RET();
 }
 

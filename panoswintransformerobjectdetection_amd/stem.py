@@ -160,17 +160,20 @@ def bn_fold_prm(sums, count, bn, conv_bias, training):
     C = bn.num_features
     prm = torch.empty(4, C, device=bn.weight.device, dtype=torch.float32)
     momentum = bn.momentum
+    nbt = None
     if training and bn.track_running_stats:
-        with torch.no_grad():
-            bn.num_batches_tracked += 1
-        if momentum is None:
+        if momentum is None:                          # cumulative average: the host needs the count
+            with torch.no_grad():
+                bn.num_batches_tracked += 1
             momentum = 1.0 / float(bn.num_batches_tracked)
+        else:
+            nbt = bn.num_batches_tracked              # incremented by the fold kernel
     s = None if sums is None else sums[:C]
     q = None if sums is None else sums[C:2 * C]
     cb = None if conv_bias is None else conv_bias.detach()
     _lib.call("pswin_stem_bn_fold", prm, _ptr(s), _ptr(q), float(count), _ptr(bn.weight.detach()), _ptr(bn.bias.detach()),
               _ptr(cb), float(bn.eps), float(momentum or 0.0), int(training), _ptr(bn.running_mean), _ptr(bn.running_var), C,
-              _ptr(prm))
+              _ptr(prm), _ptr(nbt))
     return prm
 
 
