@@ -187,6 +187,12 @@ int pswin_ln_nchw_fwd(const float* x, const float* gamma, const float* beta, flo
 int pswin_ln_nchw_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                       const float* dres, float* dx, float* dgamma, float* dbeta, float* workspace, int B, int S, int C,
                       void* stream);
+/* The same with a second output: ex_bf16 [B, S, C] = bf16(ex_scale[b] * dx[b]) (ex_scale: f32 [B] DropPath factors or NULL = 1) -- the
+ * gradient that flows into the MLP branch which closes the stage (x + DropPath(mlp(norm2(x))), HOT:536, followed by norm{i}, HOT:975):
+ * the backward of pswin_window_scatter_add's cast, written in the pass that produces dx. */
+int pswin_ln_nchw_bwd_ex(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                         const float* dres, float* dx, float* dgamma, float* dbeta, float* workspace, void* ex_bf16,
+                         const float* ex_scale, int B, int S, int C, void* stream);
 
 /* Workspace elements for the LayerNorm backward kernels over `rows` walked rows of width C. */
 int pswin_ln_workspace(long long rows, int C);

@@ -140,12 +140,15 @@ class PanoSwinTransformerBlock(nn.Module, DoubleModeModule):
         self.mlp = Mlp(dim, int(dim * mlp_ratio))
         self.pano_mode = pano_mode
 
-    def forward(self, x, H, W, cd, dp_scales=None, pre=None, nxt=None, nxt_scales=None):
+    def forward(self, x, H, W, cd, dp_scales=None, pre=None, nxt=None, nxt_scales=None, end_norm=None):
         """dp_scales: this block's two DropPath factor vectors ([2, B], from one batched draw for the whole network, see
         SimplePanoSwinTransformer.forward) or None: draw them here.
         pre: (win, x) = this block's norm1 + shift + pad + partition already done by the previous block's closing kernel.
         nxt (+ nxt_scales): the next block of the stage if this block's closing residual add should also run ITS norm1 + partition
-        (ops.scatter_add_layer_norm(out=...)); the return value is then that block's `pre` instead of the residual stream."""
+        (ops.scatter_add_layer_norm(out=...)); the return value is then that block's `pre` instead of the residual stream.
+        end_norm: the stage's output LayerNorm if this block closes the stage and its residual add should run together with that norm
+        (ops.scatter_add_layer_norm_nchw); the return value is then (normed NCHW map, residual stream), or (None, residual stream)
+        where the fused form does not apply."""
         if pre is None:
             B, S, C = x.shape
         else:
@@ -153,7 +156,8 @@ class PanoSwinTransformerBlock(nn.Module, DoubleModeModule):
         assert S == H * W, "input feature has wrong size"
         if self.generic:                          # window_size != 7 / head_dim != 32 / dropout: plain torch ops
             with torch.autocast("cuda", dtype=torch.bfloat16, enabled=(cd == torch.bfloat16 and x.is_cuda)):
-                return fallback.block_forward(self, x, H, W, self.attn_drop, self.drop).float()
+                out = fallback.block_forward(self, x, H, W, self.attn_drop, self.drop).float()
+            return (None, out) if end_norm is not None else out
         dev = x.device if pre is None else pre[1].device
         pano = bool(self.pano_mode)
         wmap, inv, nW = ops.window_maps(pano, H, W, self.shift_size, dev)
@@ -208,6 +212,10 @@ class PanoSwinTransformerBlock(nn.Module, DoubleModeModule):
             return ops.scatter_add_layer_norm(y, x, ident, None, s2, self.mlp.fc2.bias, nxt.norm1.weight, nxt.norm1.bias, nxt.norm1.eps, cd,
                                               res_bias=nxt.attn.proj.bias, res_scale=s1n,
                                               out=(inv_n, nW_n * WTOK, ops.window_pads(npano, H, W, nxt.shift_size, dev)))
+        if end_norm is not None:
+            if fuse and ops.scatter_add_layer_norm_nchw_supported(y, x):
+                return ops.scatter_add_layer_norm_nchw(y, x, s2, self.mlp.fc2.bias, end_norm.weight, end_norm.bias, end_norm.eps, H, W)
+            return None, ops.window_scatter_add(y, x, ident, ident, s2, self.mlp.fc2.bias if fuse else None, True)
         return ops.window_scatter_add(y, x, ident, ident, s2, self.mlp.fc2.bias if fuse else None, True)   # x + DropPath(mlp): one row kernel
 
     def drop_path_scales(self, x, dp_scales):
@@ -326,7 +334,7 @@ class BasicLayer(nn.Module, DoubleModeModule):
 
     def forward(self, x, H, W, cd, out_norm=None, dp_scales=None):
         """-> (stage output [normed by out_norm if given], H, W, input of the next stage, its H, W)"""
-        pre = None
+        pre = y_end = None
         for i, blk in enumerate(self.blocks):
             is_blk = isinstance(blk, PanoSwinTransformerBlock)
             sc = dp_scales[i] if (dp_scales is not None and is_blk) else None
@@ -337,13 +345,19 @@ class BasicLayer(nn.Module, DoubleModeModule):
             nxt = self.blocks[i + 1] if i + 1 < len(self.blocks) else None
             if nxt is not None and not blk.joins_with(nxt, cd, dp_scales is not None, x.shape[-1] if pre is None else pre[1].shape[-1]):
                 nxt = None
-            out = blk(x, H, W, cd, sc, pre, nxt, dp_scales[i + 1] if (nxt is not None and dp_scales is not None) else None)
+            last = nxt is None and i + 1 == len(self.blocks) and out_norm is not None
+            out = blk(x, H, W, cd, sc, pre, nxt, dp_scales[i + 1] if (nxt is not None and dp_scales is not None) else None,
+                      out_norm if last else None)
             if nxt is not None:
                 pre, x = out, None
+            elif last:
+                pre, (y_end, x) = None, out         # the stage's closing residual add ran together with its output norm (or y_end is None)
             else:
                 pre, x = None, out
         y = x
-        if out_norm is not None:                    # output norm first: the downsample branch's gradient then joins
+        if out_norm is not None and y_end is not None:
+            y = y_end
+        elif out_norm is not None:                  # output norm first: the downsample branch's gradient then joins
             if self.downsample is not None:         # the stream inside the norm's backward kernel; NCHW written directly
                 y, x = ops.layer_norm_nchw(x, out_norm.weight, out_norm.bias, out_norm.eps, H, W, passthrough=True)
             else:

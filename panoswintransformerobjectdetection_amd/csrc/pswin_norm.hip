@@ -443,7 +443,8 @@ __global__ __launch_bounds__(THREADS) void ln_nchw_bwd_kernel(const float* __res
                                                               const float* __restrict__ mean, const float* __restrict__ rstd,
                                                               const float* __restrict__ gamma, const float* __restrict__ dres,
                                                               float* __restrict__ dx, float* __restrict__ part,
-                                                              long long rows, int S, int C) {
+                                                              long long rows, int S, int C, void* __restrict__ ex,
+                                                              const float* __restrict__ ex_scale) {
     constexpr int RPB = THREADS / L;
     constexpr int Q = RPB / 4;
     extern __shared__ float tile[];                 // [RPB][C + 4] then the partial-sum staging
@@ -494,6 +495,9 @@ __global__ __launch_bounds__(THREADS) void ln_nchw_bwd_kernel(const float* __res
                 f32x4 v = (g[k] - s1 - xh[k] * s2) * rs_;
                 if (dres) v = v + *reinterpret_cast<const f32x4*>(dres + (size_t)row * C + 4 * ch);
                 *reinterpret_cast<f32x4*>(dx + (size_t)row * C + 4 * ch) = v;
+                // ex (round 4): bf16(scale[b] * dx) in token order -- the gradient of the stage's closing MLP branch (the backward of
+                // window_scatter_add's cast), written while dx is in registers instead of by a pswin_window_gather pass
+                if (ex) store4<PSWIN_BF16>(ex, (size_t)row * C + 4 * (size_t)ch, ex_scale ? v * ex_scale[b] : v);
             }
         }
     }
@@ -847,12 +851,12 @@ extern "C" int pswin_ln_nchw_fwd(const float* x, const float* gamma, const float
     PSWIN_LAUNCH_RET();
 }
 
-extern "C" int pswin_ln_nchw_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
-                                 const float* dres, float* dx, float* dgamma, float* dbeta, float* workspace, int B, int S,
-                                 int C, void* stream) {
+extern "C" int pswin_ln_nchw_bwd_ex(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                                    const float* dres, float* dx, float* dgamma, float* dbeta, float* workspace, void* ex_bf16,
+                                    const float* ex_scale, int B, int S, int C, void* stream) {
     PSWIN_CHECK_ARG(dy && x && mean && rstd && gamma && dx && workspace && B > 0 && pswin_ln_nchw_supported(S, C));
     PSWIN_CHECK_ARG((dgamma && dbeta) || (!dgamma && !dbeta));
-    PSWIN_CHECK_ARG(aligned16(dy) && aligned16(x) && aligned16(dx) && aligned16(gamma) && aligned16(dres));
+    PSWIN_CHECK_ARG(aligned16(dy) && aligned16(x) && aligned16(dx) && aligned16(gamma) && aligned16(dres) && aligned16(ex_bf16));
     const int L = pick_lanes(C), rpb = THREADS / L;
     const long long rows = (long long)B * S;
     const int blocks = bwd_blocks(rows, L);
@@ -860,7 +864,7 @@ extern "C" int pswin_ln_nchw_bwd(const float* dy, const float* x, const float* m
 #define PSWIN_LN_NCHW_B(LL)                                                                                              \
     case LL:                                                                                                             \
         hipLaunchKernelGGL((ln_nchw_bwd_kernel<LL, 4>), dim3(blocks), dim3(THREADS), lds, (hipStream_t)stream, dy, x, mean, \
-                           rstd, gamma, dres, dx, workspace, rows, S, C);                                                \
+                           rstd, gamma, dres, dx, workspace, rows, S, C, ex_bf16, ex_scale);                             \
         break;
     switch (L) {
         PSWIN_LN_NCHW_B(2) PSWIN_LN_NCHW_B(4) PSWIN_LN_NCHW_B(8) PSWIN_LN_NCHW_B(16) PSWIN_LN_NCHW_B(32) PSWIN_LN_NCHW_B(64)
@@ -869,4 +873,10 @@ extern "C" int pswin_ln_nchw_bwd(const float* dy, const float* x, const float* m
 #undef PSWIN_LN_NCHW_B
     if (dgamma) launch_colsum_seg(workspace, blocks, C, 2, dgamma, dbeta, nullptr, (hipStream_t)stream);
     PSWIN_LAUNCH_RET();
+}
+
+extern "C" int pswin_ln_nchw_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
+                                 const float* dres, float* dx, float* dgamma, float* dbeta, float* workspace, int B, int S,
+                                 int C, void* stream) {
+    return pswin_ln_nchw_bwd_ex(dy, x, mean, rstd, gamma, dres, dx, dgamma, dbeta, workspace, nullptr, nullptr, B, S, C, stream);
 }

@@ -644,6 +644,61 @@ class _LayerNormNCHW(torch.autograd.Function):
         return dx, sums[:C], sums[C:], None, None, None, None
 
 
+class _ScatterAddLayerNormNCHW(torch.autograd.Function):
+    """The end of a stage in one autograd node: x = resid + scale_b * (y + bias) (the closing MLP branch of the last block, HOT:536;
+    pswin_window_scatter_add with the identity map) followed by the output norm written as NCHW (pswin_ln_nchw_fwd, HOT:975-977).
+    Returns (normed NCHW map, x).  Backward: ONE pswin_ln_nchw_bwd_ex launch yields d(resid) (with the gradient that reaches x from the
+    next stage folded in, as layer_norm_nchw(passthrough=True)) AND d(y) = bf16(scale_b * dx) -- the cast that window_scatter_add's
+    backward otherwise runs as a pass of its own.  The bias gradient is obtained elsewhere (norm2's backward, res_bias)."""
+
+    @staticmethod
+    def forward(ctx, y, resid, scale, bias, gamma, beta, eps, H, W):
+        B, S, C = resid.shape
+        b = None if bias is None else bias.detach().float().contiguous()
+        x = _scatter_raw(y.contiguous(), identity_map(S, resid.device), resid.contiguous(), scale, S, resid.dtype, b)
+        out = torch.empty(B, C, H, W, dtype=torch.float32, device=x.device)
+        mean = torch.empty(B, S, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        call("pswin_ln_nchw_fwd", x, ptr(x), ptr(gamma), ptr(beta), float(eps), ptr(out), ptr(mean), ptr(rstd), B, S, C,
+             algo_bytes=2 * x.numel() * 4)
+        ctx.save_for_backward(x, gamma, mean, rstd, scale)
+        ctx.owners = (gamma, beta)
+        ctx.y_dtype = y.dtype
+        return out, x
+
+    @staticmethod
+    def backward(ctx, dout, dres):
+        x, gamma, mean, rstd, scale = ctx.saved_tensors
+        B, S, C = x.shape
+        if dout is None:                                  # only the residual stream was used downstream
+            dx = dres.float().contiguous()
+            dy = _gather_raw(dx, identity_map(S, x.device), scale, S, ctx.y_dtype)
+            return dy, dx, None, None, torch.zeros_like(gamma), torch.zeros_like(gamma), None, None, None
+        dout = dout.float().contiguous()
+        if dres is not None:
+            dres = dres.float().contiguous()
+        dx = torch.empty_like(x)
+        ex = torch.empty(B, S, C, dtype=torch.bfloat16, device=x.device)
+        lib = _lib.load()
+        ws = torch.empty(lib.pswin_ln_workspace(B * S, C), dtype=torch.float32, device=x.device)
+        call("pswin_ln_nchw_bwd_ex", x, ptr(dout), ptr(x), ptr(mean), ptr(rstd), ptr(gamma), ptr(dres), ptr(dx), None, None,
+             ptr(ws), ptr(ex), ptr(scale), B, S, C, timed_as="pswin_ln_nchw_bwd",
+             algo_bytes=(3 if dres is None else 4) * x.numel() * 4 + 2 * x.numel())
+        sums = sum_rows(ws, lib.pswin_ln_partial_rows(B * S, C), 2 * C, owners=ctx.owners)
+        return ex.to(ctx.y_dtype), dx, None, None, sums[:C], sums[C:], None, None, None
+
+
+def scatter_add_layer_norm_nchw_supported(y, resid):
+    """bf16 branch rows, fp32 residual stream, a shape the NCHW LayerNorm kernels tile"""
+    return (LN_FUSED_MOVES and y.dtype == torch.bfloat16 and resid.dtype == torch.float32 and y.shape == resid.shape
+            and bool(_lib.load().pswin_ln_nchw_supported(resid.shape[1], resid.shape[2])))
+
+
+def scatter_add_layer_norm_nchw(y, resid, scale, bias, gamma, beta, eps, H, W):
+    """(LayerNorm_NCHW(x), x) with x = resid + scale_b * (y + bias): see _ScatterAddLayerNormNCHW"""
+    return _ScatterAddLayerNormNCHW.apply(y, resid, scale, bias, gamma, beta, eps, H, W)
+
+
 def layer_norm_nchw(x, gamma, beta, eps, H, W, passthrough=False):
     """LayerNorm over the channels of x [B, H*W, C] (fp32) returned as a contiguous NCHW map [B, C, H, W]: the output
     norms of the backbone (HOT:975-977) without the separate transpose pass, forward and backward.  Falls back to

@@ -196,6 +196,37 @@ def test_layer_norm_gather_with_added_rows_equals_the_separate_addition(ops, C, 
         ops.layer_norm_gather(x.to(DEV), gamma.to(DEV), beta.to(DEV), 1e-5, out_dtype=torch.float32, add_rows=rows[:-1].to(DEV))
 
 
+@pytest.mark.parametrize("H,W,C", [(16, 32, 96), (8, 16, 384), (32, 64, 192)])
+@pytest.mark.parametrize("downstream", [True, False])
+def test_stage_end_residual_add_with_the_output_norm_equals_the_two_separate_ops(ops, H, W, C, downstream):
+    """ops.scatter_add_layer_norm_nchw (the closing MLP residual add of a stage + norm{i} as NCHW, whose backward kernel also writes the
+    branch gradient bf16(scale_b dx): pswin_ln_nchw_bwd_ex) against window_scatter_add followed by layer_norm_nchw: bitwise."""
+    B, S = 3, H * W
+    torch.manual_seed(H + C)
+    y = torch.randn(B, S, C, device=DEV).to(torch.bfloat16)
+    resid = torch.randn(B, S, C, device=DEV)
+    scale = torch.tensor([1.25, 0.0, 1.25], device=DEV)
+    bias = torch.randn(C, device=DEV)
+    gamma, beta = torch.rand(C, device=DEV) + 0.5, torch.randn(C, device=DEV)
+    g_out, g_x = torch.randn(B, C, H, W, device=DEV), torch.randn(B, S, C, device=DEV)
+    assert ops.scatter_add_layer_norm_nchw_supported(y, resid)
+    ident = ops.identity_map(S, DEV)
+    res = []
+    for fused in (False, True):
+        yd, rd = y.clone().requires_grad_(True), resid.clone().requires_grad_(True)
+        gd, bd = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        if fused:
+            out, x = ops.scatter_add_layer_norm_nchw(yd, rd, scale, bias, gd, bd, 1e-5, H, W)
+        else:
+            x0 = ops.window_scatter_add(yd, rd, ident, ident, scale, bias, True)
+            out, x = ops.layer_norm_nchw(x0, gd, bd, 1e-5, H, W, passthrough=True)
+        loss = (out * g_out).sum() + ((x * g_x).sum() if downstream else 0.0)
+        loss.backward()
+        res.append((out.detach(), x.detach(), yd.grad, rd.grad, gd.grad, bd.grad))
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+
+
 @pytest.mark.parametrize("H,W,C", [(5, 7, 32), (16, 32, 96), (8, 16, 384), (13, 25, 192)])
 @pytest.mark.parametrize("ydt", [torch.float32, torch.bfloat16])
 def test_layer_norm_patch_merge(ops, H, W, C, ydt):
