@@ -184,6 +184,12 @@ int pswin_scatter_add_ln_fwd_map(const void* win, int win_dtype, const int32_t* 
 int pswin_ln_nchw_supported(int S, int C);
 int pswin_ln_nchw_fwd(const float* x, const float* gamma, const float* beta, float eps, float* y, float* mean, float* rstd,
                       int B, int S, int C, void* stream);
+/* The same with the residual add that closes the stage in front of it (HOT:536 followed by 975-977):
+ *   x1[b][t] = x[b][t] + scale[b] * (win[b][t] + bias)   (win: bf16 [B, S, C] in token order, scale: f32 [B] or NULL, bias: f32 [C] or NULL),
+ * written to x1 and normalised in the same pass; bitwise pswin_window_scatter_add followed by pswin_ln_nchw_fwd.  win == NULL: plain. */
+int pswin_scatter_add_ln_nchw_fwd(const void* win_bf16, const float* x, const float* scale, const float* bias, float* x1,
+                                  const float* gamma, const float* beta, float eps, float* y, float* mean, float* rstd, int B, int S,
+                                  int C, void* stream);
 int pswin_ln_nchw_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,
                       const float* dres, float* dx, float* dgamma, float* dbeta, float* workspace, int B, int S, int C,
                       void* stream);

@@ -38,6 +38,7 @@ _PROTOTYPES = {
     "pswin_ln_nchw_supported": [_i, _i],
     "pswin_ln_nchw_fwd": [_vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _vp],
     "pswin_ln_nchw_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "pswin_scatter_add_ln_nchw_fwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _vp],
     "pswin_ln_nchw_bwd_ex": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp],
     "pswin_ln_workspace": [ctypes.c_longlong, _i],
     "pswin_ln_patch_merge_fwd": [_vp, _i, _vp, _vp, _f, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp],

@@ -382,12 +382,18 @@ template <int L, int NCH>
 __global__ __launch_bounds__(THREADS) void ln_nchw_fwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                                               const float* __restrict__ beta, float eps,
                                                               float* __restrict__ y, float* __restrict__ mean,
-                                                              float* __restrict__ rstd, int S, int C) {
+                                                              float* __restrict__ rstd, int S, int C,
+                                                              const unsigned short* __restrict__ win, const float* __restrict__ scale,
+                                                              const float* __restrict__ bias, float* __restrict__ x1) {
     constexpr int RPB = THREADS / L;
     extern __shared__ float tile[];                 // [C][RPB + 1]
     const int lane = threadIdx.x % L, rsub = threadIdx.x / L;
     const long long row = (long long)blockIdx.x * RPB + rsub;       // grid covers B * S exactly
     const int nchunks = C / 4;
+    // win != nullptr (round 4): the rows are x1 = x + scale_b * (win + bias) -- the residual add that closes a stage (x: the shortcut,
+    // win: the bf16 MLP branch in token order) -- written to x1 and normalised in the same pass; the arithmetic and its order are those
+    // of window_scatter_add_kernel (as in ln_add_fwd_kernel): bitwise the same x1
+    const float sc = (win && scale) ? scale[(long long)blockIdx.x * RPB / S] : 1.0f;
     f32x4 v[NCH];
     float s = 0.f;
 #pragma unroll
@@ -395,7 +401,16 @@ __global__ __launch_bounds__(THREADS) void ln_nchw_fwd_kernel(const float* __res
         const int ch = lane + k * L;
         v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (ch < nchunks) {
-            v[k] = *reinterpret_cast<const f32x4*>(x + (size_t)row * C + 4 * ch);
+            if (win) {
+                f32x4 val = load4<PSWIN_BF16>(win, (size_t)row * C + 4 * (size_t)ch);
+                if (bias) val = val + *reinterpret_cast<const f32x4*>(bias + 4 * (size_t)ch);
+                if (scale) val = val * sc;
+                val = val + *reinterpret_cast<const f32x4*>(x + (size_t)row * C + 4 * ch);
+                *reinterpret_cast<f32x4*>(x1 + (size_t)row * C + 4 * (size_t)ch) = val;
+                v[k] = val;
+            } else {
+                v[k] = *reinterpret_cast<const f32x4*>(x + (size_t)row * C + 4 * ch);
+            }
             s += (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
         }
     }
@@ -830,10 +845,13 @@ extern "C" int pswin_ln_nchw_supported(int S, int C) {
     return (rpb >= 4 && S % rpb == 0) ? 1 : 0;
 }
 
-extern "C" int pswin_ln_nchw_fwd(const float* x, const float* gamma, const float* beta, float eps, float* y, float* mean,
-                                 float* rstd, int B, int S, int C, void* stream) {
+extern "C" int pswin_scatter_add_ln_nchw_fwd(const void* win_bf16, const float* x, const float* scale, const float* bias, float* x1,
+                                             const float* gamma, const float* beta, float eps, float* y, float* mean, float* rstd,
+                                             int B, int S, int C, void* stream) {
+    const void* win = win_bf16;
     PSWIN_CHECK_ARG(x && gamma && beta && y && mean && rstd && B > 0 && pswin_ln_nchw_supported(S, C));
     PSWIN_CHECK_ARG(aligned16(x) && aligned16(y) && aligned16(gamma) && aligned16(beta));
+    PSWIN_CHECK_ARG(win ? (x1 && aligned16(win) && aligned16(x1) && aligned16(bias)) : (!x1 && !scale && !bias));
     const int L = pick_lanes(C), rpb = THREADS / L;
     const long long rows = (long long)B * S;
     const unsigned grid = (unsigned)(rows / rpb);
@@ -841,7 +859,7 @@ extern "C" int pswin_ln_nchw_fwd(const float* x, const float* gamma, const float
 #define PSWIN_LN_NCHW_F(LL)                                                                                               \
     case LL:                                                                                                              \
         hipLaunchKernelGGL((ln_nchw_fwd_kernel<LL, 4>), dim3(grid), dim3(THREADS), lds, (hipStream_t)stream, x, gamma, beta, \
-                           eps, y, mean, rstd, S, C);                                                                     \
+                           eps, y, mean, rstd, S, C, reinterpret_cast<const unsigned short*>(win), scale, bias, x1);       \
         break;
     switch (L) {
         PSWIN_LN_NCHW_F(2) PSWIN_LN_NCHW_F(4) PSWIN_LN_NCHW_F(8) PSWIN_LN_NCHW_F(16) PSWIN_LN_NCHW_F(32) PSWIN_LN_NCHW_F(64)
@@ -849,6 +867,11 @@ extern "C" int pswin_ln_nchw_fwd(const float* x, const float* gamma, const float
     }
 #undef PSWIN_LN_NCHW_F
     PSWIN_LAUNCH_RET();
+}
+
+extern "C" int pswin_ln_nchw_fwd(const float* x, const float* gamma, const float* beta, float eps, float* y, float* mean,
+                                 float* rstd, int B, int S, int C, void* stream) {
+    return pswin_scatter_add_ln_nchw_fwd(nullptr, x, nullptr, nullptr, nullptr, gamma, beta, eps, y, mean, rstd, B, S, C, stream);
 }
 
 extern "C" int pswin_ln_nchw_bwd_ex(const float* dy, const float* x, const float* mean, const float* rstd, const float* gamma,

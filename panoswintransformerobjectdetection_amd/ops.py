@@ -645,8 +645,8 @@ class _LayerNormNCHW(torch.autograd.Function):
 
 
 class _ScatterAddLayerNormNCHW(torch.autograd.Function):
-    """The end of a stage in one autograd node: x = resid + scale_b * (y + bias) (the closing MLP branch of the last block, HOT:536;
-    pswin_window_scatter_add with the identity map) followed by the output norm written as NCHW (pswin_ln_nchw_fwd, HOT:975-977).
+    """The end of a stage in one autograd node and one forward kernel (pswin_scatter_add_ln_nchw_fwd): x = resid + scale_b * (y + bias)
+    (the closing MLP branch of the last block, HOT:536) and the output norm of x written as NCHW (HOT:975-977).
     Returns (normed NCHW map, x).  Backward: ONE pswin_ln_nchw_bwd_ex launch yields d(resid) (with the gradient that reaches x from the
     next stage folded in, as layer_norm_nchw(passthrough=True)) AND d(y) = bf16(scale_b * dx) -- the cast that window_scatter_add's
     backward otherwise runs as a pass of its own.  The bias gradient is obtained elsewhere (norm2's backward, res_bias)."""
@@ -655,12 +655,13 @@ class _ScatterAddLayerNormNCHW(torch.autograd.Function):
     def forward(ctx, y, resid, scale, bias, gamma, beta, eps, H, W):
         B, S, C = resid.shape
         b = None if bias is None else bias.detach().float().contiguous()
-        x = _scatter_raw(y.contiguous(), identity_map(S, resid.device), resid.contiguous(), scale, S, resid.dtype, b)
+        y, resid = y.contiguous(), resid.contiguous()
+        x = torch.empty_like(resid)
         out = torch.empty(B, C, H, W, dtype=torch.float32, device=x.device)
         mean = torch.empty(B, S, dtype=torch.float32, device=x.device)
         rstd = torch.empty_like(mean)
-        call("pswin_ln_nchw_fwd", x, ptr(x), ptr(gamma), ptr(beta), float(eps), ptr(out), ptr(mean), ptr(rstd), B, S, C,
-             algo_bytes=2 * x.numel() * 4)
+        call("pswin_scatter_add_ln_nchw_fwd", x, ptr(y), ptr(resid), ptr(scale), ptr(b), ptr(x), ptr(gamma), ptr(beta), float(eps),
+             ptr(out), ptr(mean), ptr(rstd), B, S, C, timed_as="pswin_ln_nchw_fwd", algo_bytes=x.numel() * (2 + 3 * 4))
         ctx.save_for_backward(x, gamma, mean, rstd, scale)
         ctx.owners = (gamma, beta)
         ctx.y_dtype = y.dtype
