@@ -481,37 +481,51 @@ __global__ __launch_bounds__(TWG, 2) void stem_conv3_bwd_kernel(const void* __re
 }
 
 // ---------------------------------------------------------------------------------------------
-// B3: conv3 weight gradient  dW3[out][tap][in] = sum_tokens dtok[token][out] * a2[token, tap][in], a2 = relu(bn2 y2)
-// recomputed on load.  Workgroup = one tap row dy and a range of 32-token contraction steps; per step the 512 threads
-// stage a2 of the row's 4 taps (16 KB of y2, BN + ReLU applied in registers) and the d-token tile into LDS (double
-// buffered; the next step's global loads are in flight during the MFMAs); wave = (tap dx, input-channel half).
+// B3: conv3 weight gradient  dW3[out][tap][in] = sum_tokens dtok[token][out] * a2[token, tap][in], a2 = relu(bn2 y2).
+// Workgroup = one tap row dy and a range of 32-token contraction steps; wave = (tap dx, input-channel half).
+// Round 4 (end): a step's operands -- the raw y2 rows of the 4 taps (16 KB) and the d-token tile (32 rows of 192 B in 256-byte LDS rows)
+// -- go global -> LDS by LDS-DMA into a THREE-stage ring, two steps ahead of the MFMAs (counted vmcnt, one raw s_barrier per step, as
+// pswin_gemm_tn.hip), and BatchNorm + ReLU are applied to the transposed fragment a lane reads (one channel per lane: two scalars
+// instead of 16 registers of coefficients) -- the same values, rounded the same way, as normalising before the LDS store.  Before, the
+// rows were staged through registers and a workgroup had ONE step in flight (bytes in flight / latency: 2.8, then 3.5 TB/s with two
+// workgroups per CU).  No register load is left inside the loop (hipcc puts s_waitcnt vmcnt(0) in front of a loop-carried load), and all
+// LDS fragment reads are inline asm (hipcc orders the ds_read_tr16 builtin behind every LDS-DMA in flight with s_waitcnt vmcnt(0)).
+// LDS images: y2 rows off128 (chunk ^ (token & 7), applied on the DMA's source side); d rows: 16 chunks of 16 B, chunk ^ 2 (row & 7),
+// chunks 12..15 zero -- conflict-free for the transposed reads of both.
 // ---------------------------------------------------------------------------------------------
-constexpr int DTT_LD = 224;                         // 96 bf16 + 32 bytes: transposed reads conflict free
-constexpr int WG3_A2 = 4 * 32 * 128;                // a2 tiles of the 4 taps: [dx][32 tokens][64 ch] (off128)
-constexpr int WG3_BUF = WG3_A2 + 32 * DTT_LD;       // 23552 per buffer
+constexpr int WG3_A2 = 4 * 32 * 128;                // y2 rows of the 4 taps: [dx][32 tokens][64 ch]
+constexpr int WG3_DT = 32 * 256;                    // d-token tile
+constexpr int WG3_STAGE = WG3_A2 + WG3_DT;          // 24,576 B
+constexpr int WG3_ST = 3;                           // ring stages
+constexpr int WG3_LDS = WG3_ST * WG3_STAGE;         // 73,728 B (dynamic): two workgroups per CU
 constexpr int WG3_TILES = 2 * 6;                    // accumulator tiles per wave
 constexpr int WG3_OUT = TNW * WG3_TILES * 256;       // floats per workgroup partial: [wave][nt][mt][e][lane]
+typedef __attribute__((address_space(3))) void wg3_lds_void;
 
-__global__ __launch_bounds__(TWG) void stem_conv3_wgrad_kernel(const void* __restrict__ dtok, const void* __restrict__ y2,
-                                                              const float* __restrict__ scale2, const float* __restrict__ shift2,
-                                                              int H, int W, int M, int steps_per_wg,
-                                                              float* __restrict__ partial) {
-    __shared__ __attribute__((aligned(16))) char smem[2 * WG3_BUF];
+template <int OFF>
+__device__ inline void wg3_tr(u32x2& dst, unsigned addr) {
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF) : "memory");
+}
+
+__global__ __launch_bounds__(TWG, 4) void stem_conv3_wgrad_kernel(const void* __restrict__ dtok, const void* __restrict__ y2,
+                                                                 const float* __restrict__ scale2, const float* __restrict__ shift2,
+                                                                 int H, int W, int M, int steps_per_wg, long long y2_bytes,
+                                                                 float* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int c = lane & 15, g = lane >> 4, q = c >> 2, p = c & 3;
     const int dx = wave & 3, nh = wave >> 2;
     const int dy = blockIdx.y;
     const int Hh = H / 4, Wh = W / 4;
-    // staging roles: thread -> (tap ldx, token tl + 16 i, 16-byte channel chunk) of the y2 rows; threads < 384 also one
-    // 16-byte chunk of the d-token tile
-    const int ldx = threadIdx.x >> 7, chunk = threadIdx.x & 7, tl0 = (threadIdx.x & 127) >> 3;
-    const int dtl = threadIdx.x / 12, dci = threadIdx.x - 12 * dtl;
-    float sc[8], sh[8];
+    // BatchNorm coefficients of this lane's channel per input-channel tile nt: channel 16 (2 nh + nt) + c.  They pass through an asm
+    // statement once they are there: otherwise hipcc waits for these two loads INSIDE the loop (a vmcnt that drains the ring)
+    float scl[2], shl[2];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        sc[j] = scale2[8 * chunk + j];
-        sh[j] = shift2[8 * chunk + j];
+    for (int nt = 0; nt < 2; ++nt) {
+        scl[nt] = scale2[16 * (2 * nh + nt) + c];
+        shl[nt] = shift2[16 * (2 * nh + nt) + c];
     }
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(scl[0]), "+v"(scl[1]), "+v"(shl[0]), "+v"(shl[1])::"memory");
     f32x4 acc[2][6];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
@@ -522,60 +536,94 @@ __global__ __launch_bounds__(TWG) void stem_conv3_wgrad_kernel(const void* __res
     int s_end = s_begin + steps_per_wg;
     if (s_end > nsteps) s_end = nsteps;
 
-    u32x4 ry[2], rd;
-    bool oky[2];
-    auto issue = [&](int st) {
-        const int tok0 = st * 32;
+    // wave-uniform buffer resources (readfirstlane: no waterfall loops around the loads)
+    auto uni = [](const void* base, long long bytes) {
+        const unsigned long long v = (unsigned long long)base;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+        return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
+                                                 __builtin_amdgcn_readfirstlane((int)bytes), 0x00020000);
+    };
+    const rsrc_t yr = uni(y2, y2_bytes), dr = uni(dtok, (long long)M * (C3 * 2));
+    // LDS-DMA roles per step and wave (three wave instructions):
+    //   y2: tap (wave & 3), token blocks 2 (wave >> 2) + {0, 1}; an instruction moves 8 tokens x 128 B, lane i -> token 8 tb + (i >> 3),
+    //       physical chunk i & 7 = logical chunk (i & 7) ^ (token & 7);
+    //   d:  rows 4 wave .. 4 wave + 3; lane i -> row 4 wave + (i >> 4), physical chunk i & 15 = logical chunk (i & 15) ^ 2 (row & 7);
+    //       logical chunks 12..15 and rows past M: out-of-range offset, zeros land in LDS.
+    const int pl = lane >> 3, lch = (lane & 7) ^ pl;
+    const int drow = 4 * wave + (lane >> 4), dlch = (lane & 15) ^ (2 * (drow & 7));
+    auto issue = [&](int st, int stage) {
+        char* base = smem + stage * WG3_STAGE;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int tok = tok0 + tl0 + 16 * i;
-            oky[i] = tok < M;
-            const int tc = oky[i] ? tok : M - 1;
-            const int b = tc / (Hh * Wh), rem = tc - b * Hh * Wh;
+        for (int j = 0; j < 2; ++j) {
+            const int tb = 2 * (wave >> 2) + j;
+            int tok = st * 32 + 8 * tb + pl;
+            tok = tok < M ? tok : M - 1;               // rows past M: any valid pixel (their d rows are zeros)
+            const int b = tok / (Hh * Wh), rem = tok - b * Hh * Wh;
             const int ty = rem / Wh, tx = rem - ty * Wh;
-            const size_t pix = ((size_t)b * H + 4 * ty + dy) * W + 4 * tx + ldx;
-            ry[i] = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(y2) + pix * 128 + 16 * chunk);
+            const unsigned pix = (unsigned)((b * H + 4 * ty + dy) * W + 4 * tx + (wave & 3));
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(yr, (wg3_lds_void*)(base + (wave & 3) * 4096 + tb * 1024), 16,
+                                                     pix * 128u + 16u * (unsigned)lch, 0, 0, 0);
         }
-        rd = u32x4{0u, 0u, 0u, 0u};
-        if (threadIdx.x < 384 && tok0 + dtl < M)
-            rd = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(dtok) + (size_t)(tok0 + dtl) * (C3 * 2) + 16 * dci);
+        const int tok = st * 32 + drow;
+        const bool in = (tok < M) & (dlch < 12);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(dr, (wg3_lds_void*)(base + WG3_A2 + wave * 1024), 16,
+                                                 in ? (unsigned)tok * (unsigned)(C3 * 2) + 16u * (unsigned)dlch : 0xFFFFFF00u, 0, 0, 0);
     };
-    auto commit = [&](int buf) {
-        char* base = smem + buf * WG3_BUF;
+    // fragment addresses (LDS byte addresses for the asm reads).  d: row 4 g + q, bytes 32 mt + 8 p -> chunk 2 mt + (p >> 1), swizzled
+    const unsigned lds0 = (unsigned)(size_t)(wg3_lds_void*)smem;
+    unsigned a_lane[6], b_lane[2];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            bf16x8 v = bn_relu8(ry[i], sc, sh);
-            if (!oky[i]) v = __builtin_bit_cast(bf16x8, u32x4{0u, 0u, 0u, 0u});
-            *reinterpret_cast<bf16x8*>(base + ldx * 32 * 128 + off128(tl0 + 16 * i, chunk)) = v;
-        }
-        if (threadIdx.x < 384) *reinterpret_cast<u32x4*>(base + WG3_A2 + dtl * DTT_LD + 16 * dci) = rd;
-    };
-    if (s_begin < s_end) {
-        issue(s_begin);
-        commit(0);
-    }
-    __syncthreads();
+    for (int mt = 0; mt < 6; ++mt)
+        a_lane[mt] = lds0 + (unsigned)(WG3_A2 + (4 * g + q) * 256 + (((2 * mt + (p >> 1)) ^ (2 * ((4 * g + q) & 7))) << 4) + (p & 1) * 8);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) b_lane[nt] = lds0 + (unsigned)(dx * 4096 + off128(4 * g + q, 2 * (2 * nh + nt) + (p >> 1)) + (p & 1) * 8);
+
+    if (s_begin < s_end) issue(s_begin, 0);
+    if (s_begin + 1 < s_end) issue(s_begin + 1, 1);
+    int stage = 0;
     for (int st = s_begin; st < s_end; ++st) {
-        const int buf = (st - s_begin) & 1;
-        if (st + 1 < s_end) issue(st + 1);
-        const char* base = smem + buf * WG3_BUF;
-        const char* a2t = base + dx * 32 * 128;
-        const char* dtt = base + WG3_A2;
-        bf16x8 a[6];
+        // step st has landed for this wave once only the younger step's three instructions are outstanding; the barrier says so for every
+        // wave, and that every wave is done reading step st - 1, whose stage the next issue overwrites
+        if (st + 1 < s_end) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (st + 2 < s_end) issue(st + 2, stage == 0 ? 2 : stage - 1);
+        const unsigned so = (unsigned)(stage * WG3_STAGE);
+        u32x2 al[6], ah[6], bl[2], bh[2];
 #pragma unroll
         for (int mt = 0; mt < 6; ++mt) {
-            const char* lo = dtt + (4 * g + q) * DTT_LD + (16 * mt + 4 * p) * 2;
-            a[mt] = tr_pair(lo, lo + 16 * DTT_LD);
+            wg3_tr<0>(al[mt], a_lane[mt] + so);
+            wg3_tr<16 * 256>(ah[mt], a_lane[mt] + so);
         }
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            const char* lo = a2t + off128(4 * g + q, 2 * (2 * nh + nt) + (p >> 1)) + (p & 1) * 8;
-            const bf16x8 b = tr_pair(lo, lo + 16 * 128);
+            wg3_tr<0>(bl[nt], b_lane[nt] + so);
+            wg3_tr<2048>(bh[nt], b_lane[nt] + so);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(al[0]), "+v"(ah[0]), "+v"(al[1]), "+v"(ah[1]), "+v"(al[2]), "+v"(ah[2]), "+v"(al[3]), "+v"(ah[3]), "+v"(al[4]),
+                       "+v"(ah[4]), "+v"(al[5]), "+v"(ah[5]), "+v"(bl[0]), "+v"(bh[0]), "+v"(bl[1]), "+v"(bh[1])
+                     :
+                     : "memory");
+        bf16x8 a[6];
+#pragma unroll
+        for (int mt = 0; mt < 6; ++mt) a[mt] = __builtin_bit_cast(bf16x8, u32x4{al[mt][0], al[mt][1], ah[mt][0], ah[mt][1]});
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            // BatchNorm + ReLU on the 8 tokens of this lane's channel (the arithmetic of bn_relu8)
+            const u32x4 raw = {bl[nt][0], bl[nt][1], bh[nt][0], bh[nt][1]};
+            u32x4 o;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const float lo = fmaxf(__builtin_fmaf(bf_lo(raw[d]), scl[nt], shl[nt]), 0.f);
+                const float hi = fmaxf(__builtin_fmaf(bf_hi(raw[d]), scl[nt], shl[nt]), 0.f);
+                o[d] = pack_bf16(lo, hi);
+            }
+            const bf16x8 b = __builtin_bit_cast(bf16x8, o);
 #pragma unroll
             for (int mt = 0; mt < 6; ++mt) acc[nt][mt] = mfma32(a[mt], b, acc[nt][mt]);
         }
-        if (st + 1 < s_end) commit(buf ^ 1);
-        __syncthreads();
+        stage = stage == WG3_ST - 1 ? 0 : stage + 1;
     }
     float* out = partial + ((size_t)blockIdx.x * gridDim.y + dy) * WG3_OUT + wave * WG3_TILES * 256;
 #pragma unroll
@@ -836,8 +884,13 @@ int pswin_stem_conv3_wgrad(const void* dtok, const void* y2, const float* scale2
     const int per = (nsteps + splits - 1) / splits;
     splits = (nsteps + per - 1) / per;
     PSWIN_CHECK_ARG((long long)splits * 4 * WG3_OUT <= (long long)pswin_stem_workspace(B, H, W));
-    hipLaunchKernelGGL(stem_conv3_wgrad_kernel, dim3(splits, 4), dim3(TWG), 0, (hipStream_t)stream, dtok, y2, scale2, shift2, H,
-                       W, (int)M, per, workspace);
+    PSWIN_CHECK_ARG((long long)B * H * W * 128 < 0xFFFFFF00ll && M * (long long)(C3 * 2) < 0xFFFFFF00ll);
+    {
+        static std::atomic<unsigned long long> configured{0};
+        if (const int rc = ensure_dynamic_lds(reinterpret_cast<const void*>(&stem_conv3_wgrad_kernel), WG3_LDS, configured)) return rc;
+    }
+    hipLaunchKernelGGL(stem_conv3_wgrad_kernel, dim3(splits, 4), dim3(TWG), WG3_LDS, (hipStream_t)stream, dtok, y2, scale2, shift2, H,
+                       W, (int)M, per, (long long)B * H * W * 128, workspace);
     if (perm)
         hipLaunchKernelGGL(colsum_perm_kernel, dim3((4 * WG3_OUT + 15) / 16), dim3(1024), 0, (hipStream_t)stream, workspace, splits,
                            4 * WG3_OUT, perm, dw3);
